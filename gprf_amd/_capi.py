@@ -1,0 +1,209 @@
+"""ctypes binding of libgprf_hip.so (include/gprf_hip.h).  The library is built in-tree by
+``gprf_amd.build``; there is no CPU fallback — if the HIP library cannot be loaded the import of the
+product path fails loudly."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+GPRF_OK, GPRF_NOT_PD = 0, 1
+N_STAGES = 7
+STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")
+DIST_IDS = {"euclidean": 0, "lld": 1}
+KERN_IDS = {"se": 0, "matern32": 1}
+MAX_UNIT = 512
+YPAD, XPAD = 64, 4
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+
+# every entry point include/gprf_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "gprf_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32]),
+    "gprf_destroy": (ctypes.c_int, [_vp]),
+    "gprf_last_error": (ctypes.c_char_p, [_vp]),
+    "gprf_set_Y": (ctypes.c_int, [_vp, _dp]),
+    "gprf_set_theta": (ctypes.c_int, [_vp, _dp, _i32]),
+    "gprf_set_blocks": (ctypes.c_int, [_vp, _i32, _i64p, _i32p]),
+    "gprf_set_neighbors": (ctypes.c_int, [_vp, _i32, _i32p]),
+    "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
+    "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
+    "gprf_eval": (ctypes.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, _dp, _i32p]),
+    "gprf_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "gprf_eval_status": (ctypes.c_int, [_vp, _i32p]),
+    "gprf_num_units": (ctypes.c_int, [_vp, _i32p, _i32p]),
+    "gprf_work_estimate": (ctypes.c_int, [_vp, _dp, _dp]),
+    "gprf_set_timing": (ctypes.c_int, [_vp, _i32]),
+    "gprf_get_timing": (ctypes.c_int, [_vp, _i32, _dp]),
+    "gprf_debug_run": (ctypes.c_int, [_vp, _dp, _i32]),
+    "gprf_debug_fetch": (ctypes.c_int, [_vp, _i32, _i32, _dp, ctypes.c_int64]),
+    "gprf_debug_unit_shape": (ctypes.c_int, [_vp, _i32, _i32p, _i32p, _i32p]),
+}
+
+_lib = None
+
+
+class GprfHipError(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(np.linalg.LinAlgError):
+    """A unit's kernel matrix failed Cholesky (the reference raises LinAlgError from jitchol,
+    gpy_linalg.py:85,97)."""
+
+    def __init__(self, msg, unit):
+        super().__init__(msg)
+        self.unit = unit
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent or stale and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and (not os.path.exists(path)):
+        _build.build()
+    if not os.path.exists(path):
+        raise GprfHipError("libgprf_hip.so is missing (%s); run `python -m gprf_amd.build`" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Context(object):
+    """Thin RAII wrapper over gprf_ctx*."""
+
+    def __init__(self, n, dx, dy, dist_id, kern_id, device=0):
+        self.lib = load()
+        self.h = _vp()
+        rc = self.lib.gprf_create(ctypes.byref(self.h), n, dx, dy, dist_id, kern_id, device)
+        if rc != GPRF_OK:
+            self.h = None
+            raise GprfHipError("gprf_create failed (%d): no usable HIP device %d, or unsupported "
+                               "shape/kernel (n=%d dx=%d dy=%d dist=%d kern=%d)" % (rc, device, n, dx, dy, dist_id, kern_id))
+        self.n, self.dx, self.dy = n, dx, dy
+        self.ncov = 2 + (dx if dist_id == 0 else 2)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gprf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise GprfHipError("%s failed (%d): %s" % (what, rc, self.lib.gprf_last_error(self.h).decode()))
+        return rc
+
+    def set_Y(self, Y):
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        assert Y.shape == (self.n, self.dy)
+        self._check(self.lib.gprf_set_Y(self.h, dptr(Y)), "gprf_set_Y")
+
+    def set_theta(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).ravel()
+        self._check(self.lib.gprf_set_theta(self.h, dptr(theta), len(theta)), "gprf_set_theta")
+
+    def set_blocks(self, block_ptr, point_idx):
+        block_ptr = np.ascontiguousarray(block_ptr, dtype=np.int64)
+        point_idx = np.ascontiguousarray(point_idx, dtype=np.int32)
+        self._check(self.lib.gprf_set_blocks(self.h, len(block_ptr) - 1, block_ptr.ctypes.data_as(_i64p),
+                                             point_idx.ctypes.data_as(_i32p)), "gprf_set_blocks")
+
+    def set_neighbors(self, pairs):
+        pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        self._check(self.lib.gprf_set_neighbors(self.h, pairs.shape[0], pairs.ctypes.data_as(_i32p)),
+                    "gprf_set_neighbors")
+
+    def set_shard(self, rank, world):
+        self._check(self.lib.gprf_set_shard(self.h, rank, world), "gprf_set_shard")
+
+    def set_unit_jitter(self, jitter):
+        if jitter is None:
+            self._check(self.lib.gprf_set_unit_jitter(self.h, 0, None), "gprf_set_unit_jitter")
+        else:
+            jitter = np.ascontiguousarray(jitter, dtype=np.float64)
+            self._check(self.lib.gprf_set_unit_jitter(self.h, len(jitter), dptr(jitter)), "gprf_set_unit_jitter")
+
+    def eval(self, X, want_gx, want_gc):
+        """-> (rc, ll, gradX or None, gradC or None, first_bad_unit)"""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.shape == (self.n, self.dx)
+        ll = ctypes.c_double(0.0)
+        gx = np.empty((self.n, self.dx)) if want_gx else None
+        gc = np.empty((self.ncov,)) if want_gc else None
+        bad = _i32(-1)
+        rc = self.lib.gprf_eval(self.h, dptr(X), 1 if want_gx else 0, 1 if want_gc else 0, ctypes.byref(ll),
+                                dptr(gx) if want_gx else None, dptr(gc) if want_gc else None, ctypes.byref(bad))
+        self._check(rc, "gprf_eval")
+        return rc, ll.value, gx, gc, bad.value
+
+    def eval_device(self, d_X_ptr, want_gx, want_gc, d_out_ptr, stream_ptr=None):
+        rc = self.lib.gprf_eval_device(self.h, _vp(d_X_ptr), 1 if want_gx else 0, 1 if want_gc else 0,
+                                       _vp(d_out_ptr), _vp(stream_ptr) if stream_ptr else None)
+        self._check(rc, "gprf_eval_device")
+        return rc
+
+    def eval_status(self):
+        bad = _i32(-1)
+        rc = self._check(self.lib.gprf_eval_status(self.h, ctypes.byref(bad)), "gprf_eval_status")
+        return rc, bad.value
+
+    def num_units(self):
+        a, b = _i32(0), _i32(0)
+        self._check(self.lib.gprf_num_units(self.h, ctypes.byref(a), ctypes.byref(b)), "gprf_num_units")
+        return a.value, b.value
+
+    def work_estimate(self):
+        f, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self.lib.gprf_work_estimate(self.h, ctypes.byref(f), ctypes.byref(b)), "gprf_work_estimate")
+        return f.value, b.value
+
+    def set_timing(self, on):
+        self._check(self.lib.gprf_set_timing(self.h, 1 if on else 0), "gprf_set_timing")
+
+    def get_timing(self):
+        ms = np.zeros(N_STAGES)
+        self._check(self.lib.gprf_get_timing(self.h, N_STAGES, dptr(ms)), "gprf_get_timing")
+        return dict(zip(STAGE_NAMES, ms.tolist()))
+
+    # ---- per-stage parity hooks (tests) ----
+    def debug_run(self, X, stop_after=6):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._check(self.lib.gprf_debug_run(self.h, dptr(X), stop_after), "gprf_debug_run")
+
+    def debug_unit_shape(self, l):
+        m, mp, g = _i32(0), _i32(0), _i32(0)
+        self._check(self.lib.gprf_debug_unit_shape(self.h, l, ctypes.byref(m), ctypes.byref(mp), ctypes.byref(g)),
+                    "gprf_debug_unit_shape")
+        return m.value, mp.value, g.value
+
+    def debug_fetch(self, l, what):
+        m, mp, _ = self.debug_unit_shape(l)
+        shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,)}[what]
+        out = np.zeros(shape)
+        self._check(self.lib.gprf_debug_fetch(self.h, l, what, dptr(out), out.size), "gprf_debug_fetch")
+        return out

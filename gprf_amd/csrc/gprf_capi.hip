@@ -1,0 +1,627 @@
+// gprf_capi.hip — host side of libgprf_hip.so: context, unit tables, workspace pools, the C ABI of
+// include/gprf_hip.h.  No torch, no Python; plain pointers and sizes.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/gprf_hip.h"
+#include "gprf_kernels.h"
+
+using namespace gprf;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n, double slack = 1.25) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = (size_t)(n * slack) + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct gprf_ctx {
+    int n = 0, dx = 0, dy = 0, dist_id = 0, kern_id = 0, device = 0, ndfn = 0, ncov = 0;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // host-side model state (what the reference keeps on the GPRF object)
+    std::vector<double> theta;
+    bool have_Y = false, have_theta = false, have_blocks = false;
+    int n_blocks = 0, n_pairs = 0;
+    std::vector<int64_t> block_ptr;
+    std::vector<int32_t> block_pts;
+    std::vector<int32_t> pairs;           // (i, j) rows
+    std::vector<double> unit_jitter;      // global unit ids
+    bool units_dirty = true;
+
+    // local units
+    int n_local = 0, max_T = 0;
+    long total_rows = 0;
+    int64_t total_mat = 0;
+    std::vector<int32_t> l_global, l_m, l_rowoff;
+    std::vector<int64_t> l_matoff;
+    double work_flops = 0, work_fill_bytes = 0;
+
+    // device state
+    DevBuf<double> d_X, d_Y, d_out;
+    DevBuf<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_info;
+    DevBuf<int64_t> d_matoff, d_slot_ptr;
+    DevBuf<double> d_weight, d_jitter, d_slot_w;
+    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart;
+    PinBuf<double> h_X, h_out;
+    PinBuf<int32_t> h_info;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev[GPRF_N_STAGES + 1] = {};
+    bool ev_valid = false;
+    bool eval_pending = false;
+};
+
+namespace {
+
+int fail(gprf_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                           \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail((c), GPRF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+inline int pad16(int m) { return (m + 15) & ~15; }
+
+UnitTab make_tab(gprf_ctx *c) {
+    UnitTab t;
+    t.m = c->d_m.p;
+    t.row_off = c->d_rowoff.p;
+    t.mat_off = c->d_matoff.p;
+    t.weight = c->d_weight.p;
+    t.jitter = c->d_jitter.p;
+    t.upt = c->d_upt.p;
+    t.n_units = c->n_local;
+    t.max_T = c->max_T;
+    return t;
+}
+
+Pools make_pools(gprf_ctx *c) {
+    Pools p;
+    p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
+    p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
+    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p;
+    return p;
+}
+
+KParams make_kparams(gprf_ctx *c) {
+    KParams k;
+    k.nv = c->theta[0];
+    k.sv = c->theta[1];
+    for (int i = 0; i < 3; ++i) k.ls[i] = (i < c->ndfn) ? c->theta[2 + i] : 1.0;
+    k.dx = c->dx;
+    k.ndfn = c->ndfn;
+    k.dy = c->dy;
+    return k;
+}
+
+// (Re)build the local unit tables after blocks / neighbours / shard / jitter changed.
+// Units: blocks 0..n_blocks-1 (gprf.py:236), then pairs in the caller's order (gprf.py:239).
+int rebuild_units(gprf_ctx *c) {
+    const int nb = c->n_blocks, np = c->n_pairs;
+    const int nu = nb + np;
+    std::vector<int> um(nu), deg(nb, 0);
+    for (int b = 0; b < nb; ++b) um[b] = (int)(c->block_ptr[b + 1] - c->block_ptr[b]);
+    for (int q = 0; q < np; ++q) {
+        int i = c->pairs[2 * q], j = c->pairs[2 * q + 1];
+        if (i < 0 || i >= nb || j < 0 || j >= nb || i == j)
+            return fail(c, GPRF_ERR_ARG, "neighbor pair refers to a block out of range");
+        um[nb + q] = um[i] + um[j];
+        deg[i]++;
+        deg[j]++;
+    }
+    for (int u = 0; u < nu; ++u)
+        if (um[u] > GPRF_MAX_UNIT) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "unit %d has %d points; the kernels accept at most %d per unit", u, um[u],
+                     GPRF_MAX_UNIT);
+            return fail(c, GPRF_ERR_ARG, buf);
+        }
+    // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy
+    std::vector<int> owner(nu, 0);
+    if (c->world > 1) {
+        std::vector<int> order(nu);
+        std::iota(order.begin(), order.end(), 0);
+        auto cost = [&](int u) { double m = um[u]; return m * m * m + 4.0 * m * m * c->dy; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+        std::vector<double> load(c->world, 0.0);
+        for (int u : order) {
+            int best = 0;
+            for (int r = 1; r < c->world; ++r)
+                if (load[r] < load[best]) best = r;
+            owner[u] = best;
+            load[best] += cost(u);
+        }
+    }
+    c->l_global.clear(); c->l_m.clear(); c->l_rowoff.clear(); c->l_matoff.clear();
+    std::vector<double> weight, jitter;
+    long rows = 0;
+    int64_t mat = 0;
+    int maxT = 0;
+    double flops = 0, fbytes = 0;
+    for (int u = 0; u < nu; ++u) {
+        if (owner[u] != c->rank) continue;
+        int m = um[u], mp = pad16(m);
+        c->l_global.push_back(u);
+        c->l_m.push_back(m);
+        c->l_rowoff.push_back((int32_t)rows);
+        c->l_matoff.push_back(mat);
+        weight.push_back(u < nb ? (double)(1 - deg[u]) : 1.0);
+        jitter.push_back((size_t)u < c->unit_jitter.size() ? c->unit_jitter[u] : 0.0);
+        rows += mp;
+        mat += (int64_t)mp * mp;
+        maxT = std::max(maxT, mp / 16);
+        flops += (double)m * m * m + 4.0 * m * m * c->dy;
+        fbytes += 8.0 * m * m;
+    }
+    const int nl = (int)c->l_global.size();
+    c->n_local = nl;
+    c->max_T = maxT;
+    c->total_rows = rows;
+    c->total_mat = mat;
+    c->work_flops = flops;
+    c->work_fill_bytes = fbytes;
+
+    // unit row -> point table and the point -> slots CSR for the deterministic gather (gprf.py:258-273)
+    std::vector<int32_t> upt((size_t)rows, -1);
+    std::vector<int64_t> slot_cnt((size_t)c->n + 1, 0);
+    for (int l = 0; l < nl; ++l) {
+        int u = c->l_global[l];
+        int32_t *dst = upt.data() + c->l_rowoff[l];
+        auto copy_block = [&](int b, int32_t *d) {
+            int64_t s = c->block_ptr[b], e = c->block_ptr[b + 1];
+            for (int64_t k = s; k < e; ++k) d[k - s] = c->block_pts[k];
+            return (int)(e - s);
+        };
+        if (u < nb) {
+            copy_block(u, dst);
+        } else {
+            int i = c->pairs[2 * (u - nb)], j = c->pairs[2 * (u - nb) + 1];
+            int ni = copy_block(i, dst);
+            copy_block(j, dst + ni);
+        }
+        for (int r = 0; r < c->l_m[l]; ++r) slot_cnt[dst[r] + 1]++;
+    }
+    std::vector<int64_t> slot_ptr((size_t)c->n + 1, 0);
+    for (int p = 0; p < c->n; ++p) slot_ptr[p + 1] = slot_ptr[p] + slot_cnt[p + 1];
+    std::vector<int32_t> slot_row((size_t)slot_ptr[c->n]);
+    std::vector<double> slot_w((size_t)slot_ptr[c->n]);
+    {
+        std::vector<int64_t> cur(slot_ptr.begin(), slot_ptr.end() - 1);
+        for (int l = 0; l < nl; ++l) {
+            const int32_t *src = upt.data() + c->l_rowoff[l];
+            for (int r = 0; r < c->l_m[l]; ++r) {
+                int64_t k = cur[src[r]]++;
+                slot_row[k] = c->l_rowoff[l] + r;
+                slot_w[k] = weight[l];
+            }
+        }
+    }
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    size_t nl1 = (size_t)std::max(nl, 1);
+    HIP_TRY(c, c->d_m.reserve(nl1));
+    HIP_TRY(c, c->d_rowoff.reserve(nl1));
+    HIP_TRY(c, c->d_matoff.reserve(nl1));
+    HIP_TRY(c, c->d_weight.reserve(nl1));
+    HIP_TRY(c, c->d_jitter.reserve(nl1));
+    HIP_TRY(c, c->d_logdet.reserve(nl1));
+    HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
+    HIP_TRY(c, c->d_info.reserve(nl1));
+    HIP_TRY(c, c->h_info.reserve(nl1));
+    HIP_TRY(c, c->d_gcpart.reserve(nl1 * (size_t)std::max(maxT, 1) * GC_SLOTS));
+    HIP_TRY(c, c->d_upt.reserve((size_t)rows + 1));
+    HIP_TRY(c, c->d_slot_ptr.reserve((size_t)c->n + 1));
+    HIP_TRY(c, c->d_slot_row.reserve(slot_row.size() + 1));
+    HIP_TRY(c, c->d_slot_w.reserve(slot_w.size() + 1));
+    HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
+    HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
+    HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
+    HIP_TRY(c, c->d_Xu.reserve((size_t)rows * XPAD + 1));
+    HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));
+    HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1));
+    HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1));
+    HIP_TRY(c, c->d_gXu.reserve((size_t)rows * XPAD + 1));
+
+    // the uploads below read pageable vectors that die at return -> synchronous copies
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (nl > 0) {
+        HIP_TRY(c, hipMemcpy(c->d_m.p, c->l_m.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_rowoff.p, c->l_rowoff.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_matoff.p, c->l_matoff.data(), nl * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_weight.p, weight.data(), nl * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_jitter.p, jitter.data(), nl * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (rows > 0)
+        HIP_TRY(c, hipMemcpy(c->d_upt.p, upt.data(), (size_t)rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_slot_ptr.p, slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!slot_row.empty()) {
+        HIP_TRY(c, hipMemcpy(c->d_slot_row.p, slot_row.data(), slot_row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_slot_w.p, slot_w.data(), slot_w.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // Y rows of every unit (Y never changes; membership does)
+    UnitTab ut = make_tab(c);
+    Pools pl = make_pools(c);
+    launch_gather_y(ut, pl, c->d_Y.p, c->dy, (int)rows, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));  // the evaluation may be enqueued on a caller's stream
+    c->units_dirty = false;
+    return GPRF_OK;
+}
+
+int check_ready(gprf_ctx *c) {
+    if (!c) return GPRF_ERR_ARG;
+    if (!c->have_Y) return fail(c, GPRF_ERR_STATE, "gprf_set_Y has not been called");
+    if (!c->have_theta) return fail(c, GPRF_ERR_STATE, "gprf_set_theta has not been called");
+    if (!c->have_blocks) return fail(c, GPRF_ERR_STATE, "gprf_set_blocks has not been called");
+    return GPRF_OK;
+}
+
+// enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug)
+int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
+                 int stop_after) {
+    if (c->units_dirty) {
+        int rc = rebuild_units(c);
+        if (rc != GPRF_OK) return rc;
+    }
+    UnitTab ut = make_tab(c);
+    Pools pl = make_pools(c);
+    KParams kp = make_kparams(c);
+    AssembleTab at{c->d_slot_ptr.p, c->d_slot_row.p, c->d_slot_w.p};
+    bool tm = c->timing;
+    if (tm && !c->ev_valid) {
+        for (int i = 0; i <= GPRF_N_STAGES; ++i) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+        c->ev_valid = true;
+    }
+    int stage = 0;
+    auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[stage], s); ++stage; };
+    mark();
+    launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
+    mark();
+    launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
+    mark();
+    if (stop_after >= 1) launch_potrf(ut, pl, s);
+    mark();
+    if (stop_after >= 2) launch_solve(ut, pl, s);
+    mark();
+    if (stop_after >= 3) launch_at(ut, pl, s);
+    mark();
+    if (stop_after >= 4 && (want_gx || want_gc)) launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, s);
+    mark();
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+    mark();
+    HIP_TRY(c, hipGetLastError());
+    // unit status -> pinned host
+    if (c->n_local > 0)
+        HIP_TRY(c, hipMemcpyAsync(c->h_info.p, c->d_info.p, c->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    c->eval_pending = true;
+    return GPRF_OK;
+}
+
+int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->eval_pending = false;
+    int bad = -1;
+    for (int l = 0; l < c->n_local; ++l)
+        if (c->h_info.p[l] != 0) { bad = c->l_global[l]; break; }
+    if (first_bad_unit) *first_bad_unit = bad;
+    if (bad >= 0) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "unit %d: kernel matrix not positive definite", bad);
+        c->err = buf;
+        return GPRF_NOT_PD;
+    }
+    return GPRF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
+                int32_t device) {
+    if (!out) return GPRF_ERR_ARG;
+    *out = nullptr;
+    if (n < 0 || dy < 1 || dy > YPAD) return GPRF_ERR_ARG;
+    bool se = (dist_id == GPRF_DIST_EUCLIDEAN && kern_id == GPRF_KERN_SE);
+    bool mt = (dist_id == GPRF_DIST_LLD && kern_id == GPRF_KERN_MATERN32);
+    if (!se && !mt) return GPRF_ERR_ARG;  // the two combinations the reference's callers use
+    if (se && (dx < 1 || dx > 3)) return GPRF_ERR_ARG;
+    if (mt && dx != 3) return GPRF_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return GPRF_ERR_HIP;
+    gprf_ctx *c = new gprf_ctx();
+    c->n = n; c->dx = dx; c->dy = dy; c->dist_id = dist_id; c->kern_id = kern_id; c->device = device;
+    c->ndfn = se ? dx : 2;
+    c->ncov = 2 + c->ndfn;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return GPRF_ERR_HIP;
+    }
+    size_t nout = 1 + (size_t)n * dx + c->ncov;
+    if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
+        c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
+        c->h_out.reserve(nout) != hipSuccess) {
+        gprf_destroy(c);
+        return GPRF_ERR_HIP;
+    }
+    *out = c;
+    return GPRF_OK;
+}
+
+int gprf_destroy(gprf_ctx *c) {
+    if (!c) return GPRF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_m.release(); c->d_rowoff.release();
+    c->d_upt.release(); c->d_slot_row.release(); c->d_info.release(); c->d_matoff.release();
+    c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
+    c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
+    c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
+    c->d_gcpart.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
+    if (c->ev_valid)
+        for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GPRF_OK;
+}
+
+const char *gprf_last_error(const gprf_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int gprf_set_Y(gprf_ctx *c, const double *Y) {
+    if (!c || !Y) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_Y.p, Y, (size_t)c->n * c->dy * sizeof(double), hipMemcpyHostToDevice));
+    c->have_Y = true;
+    c->units_dirty = true;  // Yu must be re-gathered
+    return GPRF_OK;
+}
+
+int gprf_set_theta(gprf_ctx *c, const double *theta, int32_t ntheta) {
+    if (!c || !theta) return GPRF_ERR_ARG;
+    if (ntheta != c->ncov) return fail(c, GPRF_ERR_ARG, "theta must be [noise_var, signal_var, dfn_params...]");
+    for (int i = 0; i < ntheta; ++i)
+        if (!std::isfinite(theta[i])) return fail(c, GPRF_ERR_ARG, "non-finite hyper-parameter");
+    c->theta.assign(theta, theta + ntheta);
+    c->have_theta = true;
+    return GPRF_OK;
+}
+
+int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx) {
+    if (!c || n_blocks < 0 || !block_ptr) return GPRF_ERR_ARG;
+    if (block_ptr[0] != 0) return fail(c, GPRF_ERR_ARG, "block_ptr[0] must be 0");
+    for (int b = 0; b < n_blocks; ++b)
+        if (block_ptr[b + 1] < block_ptr[b]) return fail(c, GPRF_ERR_ARG, "block_ptr must be non-decreasing");
+    int64_t tot = block_ptr[n_blocks];
+    if (tot > 0 && !point_idx) return GPRF_ERR_ARG;
+    for (int64_t k = 0; k < tot; ++k)
+        if (point_idx[k] < 0 || point_idx[k] >= c->n) return fail(c, GPRF_ERR_ARG, "point index out of range");
+    if (n_blocks != c->n_blocks) {
+        // pairs refer to block ids; a different block count invalidates them unless re-set
+        if (c->n_pairs > 0) {
+            for (int q = 0; q < 2 * c->n_pairs; ++q)
+                if (c->pairs[q] >= n_blocks) return fail(c, GPRF_ERR_STATE, "existing neighbor pairs exceed the new block count");
+        }
+    }
+    c->n_blocks = n_blocks;
+    c->block_ptr.assign(block_ptr, block_ptr + n_blocks + 1);
+    c->block_pts.assign(point_idx, point_idx + tot);
+    c->have_blocks = true;
+    c->units_dirty = true;
+    return GPRF_OK;
+}
+
+int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
+    if (!c || n_pairs < 0 || (n_pairs > 0 && !pairs_ij)) return GPRF_ERR_ARG;
+    c->n_pairs = n_pairs;
+    c->pairs.assign(pairs_ij, pairs_ij + 2 * (size_t)n_pairs);
+    c->units_dirty = true;
+    return GPRF_OK;
+}
+
+int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return GPRF_ERR_ARG;
+    c->rank = rank;
+    c->world = world;
+    c->units_dirty = true;
+    return GPRF_OK;
+}
+
+int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
+    if (!c) return GPRF_ERR_ARG;
+    if (!jitter) c->unit_jitter.clear();
+    else c->unit_jitter.assign(jitter, jitter + n_units);
+    c->units_dirty = true;
+    return GPRF_OK;
+}
+
+int gprf_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
+                     void *stream) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (!d_X || !d_out) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // table uploads in rebuild_units run on the context stream synchronously, so any stream may follow
+    return enqueue_eval(c, d_X, want_gradX, want_gradC, d_out, s, 6);
+}
+
+int gprf_eval_status(gprf_ctx *c, int32_t *first_bad_unit) {
+    if (!c) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return finish_eval(c, c->stream, first_bad_unit);
+}
+
+int gprf_eval(gprf_ctx *c, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
+              double *gradX_out, double *gradC_out, int32_t *first_bad_unit) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (!X || !ll_out || (want_gradX && !gradX_out) || (want_gradC && !gradC_out)) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    size_t nx = (size_t)c->n * c->dx;
+    size_t nout = 1 + nx + c->ncov;
+    memcpy(c->h_X.p, X, nx * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+    rc = enqueue_eval(c, c->d_X.p, want_gradX, want_gradC, c->d_out.p, s, 6);
+    if (rc != GPRF_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+    rc = finish_eval(c, s, first_bad_unit);
+    if (rc != GPRF_OK) return rc;
+    *ll_out = c->h_out.p[0];
+    if (want_gradX) memcpy(gradX_out, c->h_out.p + 1, nx * sizeof(double));
+    if (want_gradC) memcpy(gradC_out, c->h_out.p + 1 + nx, c->ncov * sizeof(double));
+    return GPRF_OK;
+}
+
+int gprf_num_units(const gprf_ctx *c, int32_t *n_total, int32_t *n_local) {
+    if (!c) return GPRF_ERR_ARG;
+    if (n_total) *n_total = c->n_blocks + c->n_pairs;
+    if (n_local) *n_local = c->units_dirty ? -1 : c->n_local;
+    return GPRF_OK;
+}
+
+int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (c->units_dirty) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        rc = rebuild_units(c);
+        if (rc != GPRF_OK) return rc;
+    }
+    if (flops) *flops = c->work_flops;
+    if (fill_bytes) *fill_bytes = c->work_fill_bytes;
+    return GPRF_OK;
+}
+
+int gprf_set_timing(gprf_ctx *c, int32_t enable) {
+    if (!c) return GPRF_ERR_ARG;
+    c->timing = enable != 0;
+    return GPRF_OK;
+}
+
+int gprf_get_timing(gprf_ctx *c, int32_t n, double *ms_out) {
+    if (!c || !ms_out || n < GPRF_N_STAGES) return GPRF_ERR_ARG;
+    if (!c->ev_valid) return fail(c, GPRF_ERR_STATE, "no timed evaluation yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev[GPRF_N_STAGES]));
+    for (int i = 0; i < GPRF_N_STAGES; ++i) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        ms_out[i] = ms;
+    }
+    return GPRF_OK;
+}
+
+int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (!X) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t nx = (size_t)c->n * c->dx;
+    memcpy(c->h_X.p, X, nx * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_eval(c, c->d_X.p, 1, 1, c->d_out.p, c->stream, stop_after);
+    if (rc != GPRF_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->eval_pending = false;
+    return GPRF_OK;
+}
+
+int gprf_debug_unit_shape(gprf_ctx *c, int32_t l, int32_t *m, int32_t *mp, int32_t *global_unit) {
+    if (!c || c->units_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
+    if (m) *m = c->l_m[l];
+    if (mp) *mp = pad16(c->l_m[l]);
+    if (global_unit) *global_unit = c->l_global[l];
+    return GPRF_OK;
+}
+
+int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t out_len) {
+    if (!c || !out || c->units_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int64_t mp = pad16(c->l_m[l]);
+    int64_t roff = c->l_rowoff[l];
+    const double *src = nullptr;
+    int64_t len = 0;
+    switch (what) {
+        case 0: src = c->d_U.p + c->l_matoff[l]; len = mp * mp; break;
+        case 1: src = c->d_W.p + c->l_matoff[l]; len = mp * mp; break;
+        case 2: src = c->d_Z.p + roff * YPAD; len = mp * YPAD; break;
+        case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;
+        case 4: src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;
+        case 5: {
+            if (out_len < 4) return GPRF_ERR_ARG;
+            double zz[4];
+            int32_t info = 0;
+            HIP_TRY(c, hipMemcpy(out + 1, c->d_logdet.p + l, sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(zz, c->d_zzpart.p + (size_t)l * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&info, c->d_info.p + l, sizeof(int32_t), hipMemcpyDeviceToHost));
+            out[2] = (zz[0] + zz[1]) + (zz[2] + zz[3]);
+            out[3] = info;
+            out[0] = -0.5 * out[2] - 0.5 * c->dy * out[1] - 0.5 * c->dy * c->l_m[l] * std::log(2.0 * M_PI);
+            return GPRF_OK;
+        }
+        default: return GPRF_ERR_ARG;
+    }
+    if (out_len < len) return GPRF_ERR_ARG;
+    if (len > 0) HIP_TRY(c, hipMemcpy(out, src, len * sizeof(double), hipMemcpyDeviceToHost));
+    return GPRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// gprf_kernels.h — shared declarations between the HIP kernels (gprf_kernels.hip) and the C-ABI host
+// layer (gprf_capi.hip).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gprf {
+
+constexpr int TILE = 16;          // MFMA f64 16x16x4 tile edge
+constexpr int MAX_MP = 512;       // largest padded unit (GPRF_MAX_UNIT)
+constexpr int MAX_T = MAX_MP / TILE;
+constexpr int YPAD = 64;          // dy padded to 4 column tiles
+constexpr int XPAD = 4;           // dx padded (dx <= 3)
+constexpr int GC_SLOTS = 8;       // per-(unit, column-tile) hyper-gradient partials
+
+// Kernel hyper-parameters, passed by value.  theta = [nv, sv, ls...] (gprf.py:160-164).
+struct KParams {
+    double nv, sv;
+    double ls[3];
+    int dx, ndfn, dy;
+};
+
+// Per-unit tables (device pointers), one entry per LOCAL unit.
+struct UnitTab {
+    const int32_t *m;        // points in the unit
+    const int32_t *row_off;  // padded-row offset: sum of mp over previous units
+    const int64_t *mat_off;  // element offset of the unit's mp x mp matrices in the U / W pools
+    const double *weight;    // Bethe weight: 1 - deg(i) for unaries, 1 for pairs
+    const double *jitter;    // extra diagonal (jitchol retry)
+    const int32_t *upt;      // [total padded rows] global point index of each unit row, -1 for padding
+    int n_units;
+    int max_T;               // max over units of mp/16
+};
+
+struct Pools {
+    double *U;     // K, overwritten by its upper Cholesky factor (row-major mp x mp per unit)
+    double *W;     // U^-T (lower triangular, row-major)
+    double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
+    double *Xu;    // gathered unit coordinates, XPAD per padded row
+    double *Yu;    // gathered unit outputs, YPAD per padded row (zero padded)
+    double *Z;     // U^-T Yu, YPAD per padded row
+    double *At;    // (K^-1 Yu)^T : per unit YPAD x mp at YPAD*row_off
+    double *gXu;   // per-unit-row gradient slab, XPAD per padded row
+    double *logdet;   // per unit
+    double *zzpart;   // per unit x 4 : partial sums of ||Z||_F^2 per Y column block
+    double *gcpart;   // per unit x max_T x GC_SLOTS
+    int32_t *info;    // per unit: 0 ok, k>0 = non-positive pivot at row k-1
+};
+
+struct AssembleTab {
+    const int64_t *slot_ptr;   // [n+1]
+    const int32_t *slot_row;   // padded-row index into gXu
+    const double *slot_w;      // unit weight
+};
+
+void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
+void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
+void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
+void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s);
+void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s);
+void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
+void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
+                 hipStream_t s);
+void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
+                     int want_gx, int want_gc, double *out, hipStream_t s);
+
+}  // namespace gprf

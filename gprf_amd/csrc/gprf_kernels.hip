@@ -1,0 +1,711 @@
+// gprf_kernels.hip — gfx950 (MI355X, CDNA4) kernels for the GPRF block-local log-likelihood/gradient path.
+//
+// One "unit" = one block or one concatenated neighbouring block pair (gprf.py:299-330).  Per unit the
+// reference computes (gprf.py:496-591)  K = k(X,X)+nv I ; chol ; K^-1 ; A = K^-1 Y ; ll ; gradX ; gradC.
+// Here every unit matrix is padded to mp = 16*T rows and the whole pipeline is written in the one GEMM
+// form the f64 MFMA (v_mfma_f64_16x16x4_f64) consumes without any transposition:
+//
+//        D[i][j] (+)= sum_k SA[k][i] * SB[k][j]        SA, SB, D all ROW-major, k = slow index
+//
+// lane l of a wave (lr = l & 15, lg = l >> 4) feeds  a = SA[4s+lg][lr],  b = SB[4s+lg][lr]  for k-step s and
+// owns D[lg + 4q][lr], q = 0..3.  Consecutive lanes therefore always touch consecutive doubles (128-B
+// segments from HBM/L2, conflict-free 256-B rows from LDS), and an accumulator register q IS the B operand
+// of k-step q of the next product (rows 4q+lg) — tiles chain through registers.
+//
+// In that form:   K = U^T U            (upper Cholesky, U row-major)              k_potrf
+//                 W = U^-T, Z = U^-T Y (forward substitution on [I | Y])          k_solve
+//                 At = Z^T W = (K^-1 Y)^T                                         k_at
+//                 M = At^T At - dy * W^T W  ( = A A^T - dy K^-1 ), reduced on the fly against
+//                 dk/dx and dk/dtheta into gradX rows and gradC partials           k_grad
+// Reference identities:  gX[p,i] = sum_q M[p,q] dk(x_p,x_q)/dx_p[i]  (gprf.py:556-573),
+//                        gC[t]   = 1/2 sum_pq M[p,q] dK_pq/dtheta_t  (gprf.py:577-584),
+//                        ll      = -1/2 ||Z||_F^2 - dy sum log U_kk - 1/2 dy m log 2pi (gprf.py:542-544).
+#include "gprf_kernels.h"
+
+namespace gprf {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl_xor(x, mask, 64); }
+
+__device__ __forceinline__ int pad16(int m) { return (m + 15) & ~15; }
+
+// ------------------------------------------------------------------------------------------------
+// distance / covariance functions (treegp side of gprf.py:333-375; definitions SURVEY.md §8a)
+// ------------------------------------------------------------------------------------------------
+constexpr double EARTH_R_KM = 6371.0;  // run_seismic.py:52
+constexpr double DEG2RAD = 0.017453292519943295769;
+constexpr double SQRT3 = 1.7320508075688772935;
+
+template <int DIST, int KERN>
+struct KernFn;
+
+// ("euclidean","se"):  d = sqrt(sum(((a-b)/l)^2)),  k = sv exp(-d*d)
+template <>
+struct KernFn<0, 0> {
+    __device__ static __forceinline__ double value(const KParams &p, const double *xi, const double *xj) {
+        double sq = 0.0;
+        for (int d = 0; d < p.dx; ++d) {
+            double diff = (xi[d] - xj[d]) / p.ls[d];
+            sq += diff * diff;
+        }
+        double r = sqrt(sq);
+        return p.sv * exp(-1.0 * r * r);
+    }
+    // k, d k(xj, xi)/d xj[d], d k / d ls[t]
+    __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
+                                                  double *dkdxj, double *dkdl) {
+        double k = value(p, xi, xj);
+        for (int d = 0; d < p.dx; ++d) {
+            double delta = xj[d] - xi[d];
+            double l = p.ls[d];
+            dkdxj[d] = -2.0 * delta / (l * l) * k;
+            dkdl[d] = 2.0 * delta * delta / (l * l * l) * k;
+        }
+        return k;
+    }
+};
+
+// great-circle pieces shared by the lld distance: a = haversine argument, g = km
+struct Hav {
+    double a, g, s1, c1, s2, c2, cli, clj, slj;
+};
+__device__ static __forceinline__ Hav haversine(const double *xi, const double *xj) {
+    Hav h;
+    double rloni = xi[0] * DEG2RAD, rlati = xi[1] * DEG2RAD;
+    double rlonj = xj[0] * DEG2RAD, rlatj = xj[1] * DEG2RAD;
+    double hl = (rlatj - rlati) / 2.0, hn = (rlonj - rloni) / 2.0;
+    h.s1 = sin(hl); h.c1 = cos(hl); h.s2 = sin(hn); h.c2 = cos(hn);
+    h.cli = cos(rlati); h.clj = cos(rlatj); h.slj = sin(rlatj);
+    double a = h.s1 * h.s1 + h.cli * h.clj * h.s2 * h.s2;
+    if (a > 1.0) a = 1.0;
+    h.a = a;
+    double dist_rad = 2.0 * asin(sqrt(a));
+    double deg = dist_rad * (180.0 / 3.14159265358979323846);
+    h.g = (deg * DEG2RAD) * EARTH_R_KM;
+    return h;
+}
+
+// ("lld","matern32"):  r = sqrt((g/l0)^2 + (dz/l1)^2),  k = sv (1 + sqrt3 r) exp(-sqrt3 r)
+template <>
+struct KernFn<1, 1> {
+    __device__ static __forceinline__ double value(const KParams &p, const double *xi, const double *xj) {
+        Hav h = haversine(xi, xj);
+        double dk = h.g / p.ls[0];
+        double dd = (xi[2] - xj[2]) / p.ls[1];
+        double r = sqrt(dk * dk + dd * dd);
+        double s3r = SQRT3 * r;
+        return p.sv * (1.0 + s3r) * exp(-s3r);
+    }
+    __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
+                                                  double *dkdxj, double *dkdl) {
+        Hav h = haversine(xi, xj);
+        double l0 = p.ls[0], l1 = p.ls[1];
+        double dk = h.g / l0;
+        double dz = xj[2] - xi[2];
+        double dd = dz / l1;
+        double r = sqrt(dk * dk + dd * dd);
+        double s3r = SQRT3 * r;
+        double e = exp(-s3r);
+        double k = p.sv * (1.0 + s3r) * e;
+        double c = -3.0 * p.sv * e;  // dk/dr = c * r ; r cancels against d r/d(.) = (.)/r
+        // g * dg/d(lon_j, lat_j): dg/da = R / sqrt(a(1-a)); zero at coincident / antipodal points
+        double gdg_lon = 0.0, gdg_lat = 0.0;
+        if (h.a > 0.0 && h.a < 1.0) {
+            double dg_da = EARTH_R_KM / sqrt(h.a * (1.0 - h.a));
+            double da_dlat = h.s1 * h.c1 - h.slj * h.cli * h.s2 * h.s2;
+            double da_dlon = h.cli * h.clj * h.s2 * h.c2;
+            gdg_lon = h.g * dg_da * da_dlon * DEG2RAD;
+            gdg_lat = h.g * dg_da * da_dlat * DEG2RAD;
+        }
+        dkdxj[0] = c * gdg_lon / (l0 * l0);
+        dkdxj[1] = c * gdg_lat / (l0 * l0);
+        dkdxj[2] = c * dz / (l1 * l1);
+        dkdl[0] = -c * h.g * h.g / (l0 * l0 * l0);
+        dkdl[1] = -c * dz * dz / (l1 * l1 * l1);
+        return k;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// gathers (gprf.py:300-302, 314-326: X[idxs], Y[idxs], vstack) into padded per-unit rows
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather_y(const int32_t *__restrict__ upt, const double *__restrict__ Y, double *__restrict__ Yu,
+                           int dy, int total_rows) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int c = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    int pt = upt[row];
+    double v = 0.0;
+    if (pt >= 0 && c < dy) v = Y[(size_t)pt * dy + c];
+    Yu[(size_t)row * YPAD + c] = v;
+}
+
+__global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__restrict__ X, double *__restrict__ Xu,
+                           int dx, int total_rows) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= total_rows) return;
+    int pt = upt[row];
+    for (int d = 0; d < XPAD; ++d) {
+        double v = 0.0;
+        if (pt >= 0 && d < dx) v = X[(size_t)pt * dx + d];
+        Xu[(size_t)row * XPAD + d] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K fill (gprf.py:333-343 -> VectorTree.kernel_matrix + nv I): 64x64 tile per workgroup, lane = column
+// so every wave-store is 512 contiguous bytes.  HBM-write bound: 8 mp^2 bytes per unit.
+// ------------------------------------------------------------------------------------------------
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int nt64) {
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m);
+    int ti = blockIdx.x / nt64, tj = blockIdx.x % nt64;
+    int r0 = ti * 64, c0 = tj * 64;
+    if (r0 >= mp || c0 >= mp) return;
+    __shared__ double xr[64 * XPAD];
+    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
+    int t = threadIdx.x;
+    {   // 64 rows x 4 coords = 256 values
+        int rr = r0 + (t >> 2);
+        xr[t] = (rr < mp) ? Xu[(size_t)rr * XPAD + (t & 3)] : 0.0;
+    }
+    int col = c0 + (t & 63);
+    double xj[XPAD];
+    for (int d = 0; d < XPAD; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XPAD + d] : 0.0;
+    __syncthreads();
+    if (col >= mp) return;
+    double *U = pl.U + ut.mat_off[u];
+    double diag_add = kp.nv + ut.jitter[u];
+    int rbase = t >> 6;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        int rl = rbase + 4 * q;
+        int row = r0 + rl;
+        if (row >= mp) break;
+        double v;
+        if (row < m && col < m) {
+            v = KernFn<DIST, KERN>::value(kp, &xr[rl * XPAD], xj);
+            if (row == col) v += diag_add;
+        } else {
+            v = (row == col) ? 1.0 : 0.0;
+        }
+        U[(size_t)row * mp + col] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blocked upper Cholesky K = U^T U, one workgroup per unit (gpy_linalg.py:77-97 jitchol -> dpotrf;
+// logdet gpy_linalg.py:234).  Per 16-row panel j:
+//   (a) wave 0 factors the 16x16 diagonal tile in registers (lane = column, cross-lane by v_readlane)
+//       and inverts it (V_jj = U_jj^-1, kept for the triangular solves);
+//   (b) row panel  U_jk = V_jj^T C_jk  by MFMA, staged into LDS (k-major rows, conflict-free);
+//   (c) trailing update  C_ik -= U_ji^T U_jk  by MFMA with both operands read from the LDS panel.
+// ------------------------------------------------------------------------------------------------
+constexpr int POTRF_WAVES = 8;
+
+__global__ __launch_bounds__(POTRF_WAVES * 64) void k_potrf(UnitTab ut, Pools pl) {
+    extern __shared__ double lds[];
+    __shared__ int s_fail;
+    int u = blockIdx.x;
+    int m = ut.m[u];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    if (m == 0) {
+        if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
+        return;
+    }
+    int mp = pad16(m), T = mp >> 4;
+    int ldp = mp + ((T & 1) ? 0 : 16);  // (ldp/16) odd: lane groups lg, lg+1 land 32 banks apart
+    double *P = lds;                    // [16][ldp] current row panel of U
+    double *Vd = lds + 16 * ldp;        // [16][16]  V_jj
+    double *U = pl.U + ut.mat_off[u];
+    double *V = pl.V + (size_t)ut.row_off[u] * 16;
+    if (threadIdx.x == 0) s_fail = 0;
+    double logsum = 0.0;
+    __syncthreads();
+
+    for (int j = 0; j < T; ++j) {
+        // ---- (a) diagonal tile: unblocked upper Cholesky + inverse, wave 0, column lr per lane ----
+        if (wave == 0) {
+            double s[16], v[16];
+            const double *Cjj = U + (size_t)(16 * j) * mp + 16 * j;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = Cjj[(size_t)i * mp + lr];
+            int bad = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double pkk = readlane_d(s[k], k);
+                if (!(pkk > 0.0)) {
+                    if (!bad) bad = 16 * j + k + 1;
+                    pkk = 1.0;
+                }
+                double d = sqrt(pkk);
+                logsum += log(d);
+                double ukc = (lr > k) ? s[k] / d : ((lr == k) ? d : 0.0);
+                s[k] = ukc;
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) {
+                    double uki = readlane_d(ukc, i);
+                    s[i] -= uki * ukc;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the readlane->SGPR live ranges per step
+            }
+            // V = U_jj^-1 (upper): back substitution, column lr per lane
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.0;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                double acc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = i + 1; k < 16; ++k) {
+                    double uik = readlane_d(s[i], k);
+                    acc -= uik * v[k];
+                }
+                double uii = readlane_d(s[i], i);
+                v[i] = (i <= lr) ? acc / uii : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 16) {
+                double *Ujj = U + (size_t)(16 * j) * mp + 16 * j;
+                double *Vj = V + (size_t)j * 256;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double uv = (i <= lr) ? s[i] : 0.0;
+                    Ujj[(size_t)i * mp + lr] = uv;
+                    Vd[i * 16 + lr] = v[i];
+                    Vj[i * 16 + lr] = v[i];
+                }
+                if (bad && lane == 0) s_fail = bad;
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
+            return;
+        }
+        // ---- (b) row panel: U_jk = V_jj^T C_jk, k > j ----
+        for (int k = j + 1 + wave; k < T; k += POTRF_WAVES) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double *Cjk = U + (size_t)(16 * j) * mp + 16 * k;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double a = Vd[(4 * s + lg) * 16 + lr];
+                double b = Cjk[(size_t)(4 * s + lg) * mp + lr];
+                acc = mfma(a, b, acc);
+            }
+            double *Ujk = U + (size_t)(16 * j) * mp + 16 * k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Ujk[(size_t)(lg + 4 * q) * mp + lr] = acc[q];
+                P[(lg + 4 * q) * ldp + 16 * k + lr] = acc[q];
+            }
+        }
+        __syncthreads();
+        // ---- (c) trailing update: C_ik -= U_ji^T U_jk, j < i <= k < T ----
+        int ntr = T - j - 1;
+        int ntile = ntr * (ntr + 1) / 2;
+        for (int t = wave; t < ntile; t += POTRF_WAVES) {
+            int a_ = 0, rem = t;
+            while (rem >= ntr - a_) { rem -= ntr - a_; ++a_; }
+            int i = j + 1 + a_, k = i + rem;
+            double *Cik = U + (size_t)(16 * i) * mp + 16 * k;
+            d4 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = Cik[(size_t)(lg + 4 * q) * mp + lr];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
+                double b = P[(4 * s + lg) * ldp + 16 * k + lr];
+                acc = mfma(a, b, acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cik[(size_t)(lg + 4 * q) * mp + lr] = acc[q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pl.logdet[u] = 2.0 * logsum;  // log|K| = 2 sum log U_kk
+        pl.info[u] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward substitution  U^T [W | Z] = [I | Yu]  (replaces dtrtri/dpotri/dpotrs of gpy_linalg.py:219-253,
+// 139-148): one workgroup per 16-column block of the right-hand side, right-looking, the block's
+// running tiles live in MFMA accumulators; only the freshly solved tile goes through LDS.
+// blockIdx.x < max_T : identity column block cb (rows >= cb only, W is lower triangular)
+// blockIdx.x >= max_T: Y column block yb = blockIdx.x - max_T (all rows)
+// ------------------------------------------------------------------------------------------------
+constexpr int SOLVE_WAVES = 4;
+constexpr int SOLVE_SLOTS = MAX_T / SOLVE_WAVES;  // 8
+
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl) {
+    __shared__ double Wr[2][256];
+    __shared__ double zred[SOLVE_WAVES];
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int bx = blockIdx.x;
+    bool is_y = bx >= ut.max_T;
+    int cb = is_y ? (bx - ut.max_T) : bx;
+    if (!is_y && cb >= T) return;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    if (T == 0) {
+        if (is_y && threadIdx.x == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
+        return;
+    }
+    const double *U = pl.U + ut.mat_off[u];
+    const double *V = pl.V + roff * 16;
+    double *W = pl.W + ut.mat_off[u];
+    double *Z = pl.Z + roff * YPAD;
+    const double *Yu = pl.Yu + roff * YPAD;
+    int r0 = is_y ? 0 : cb;
+
+    d4 acc[SOLVE_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
+        int r = r0 + wave + SOLVE_WAVES * sl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = 0.0;
+            if (r < T) {
+                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
+                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+            }
+            acc[sl][q] = v;
+        }
+    }
+    double zz = 0.0;
+    for (int r = r0; r < T; ++r) {
+        int owner = (r - r0) & (SOLVE_WAVES - 1);
+        int slot = (r - r0) / SOLVE_WAVES;
+        double *buf = Wr[r & 1];
+        if (wave == owner) {
+            const double *Vr = V + (size_t)r * 256;
+            d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
+                if (sl == slot) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) w = mfma(Vr[(4 * s + lg) * 16 + lr], acc[sl][s], w);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                buf[(lg + 4 * q) * 16 + lr] = w[q];
+                if (is_y) {
+                    Z[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr] = w[q];
+                    zz += w[q] * w[q];
+                } else {
+                    W[(size_t)(16 * r + lg + 4 * q) * mp + 16 * cb + lr] = w[q];
+                }
+            }
+        }
+        __syncthreads();
+        // update the rows below: acc_r' -= U_{r,r'}^T W_r
+        double b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = buf[(4 * s + lg) * 16 + lr];
+#pragma unroll
+        for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
+            int rp = r0 + wave + SOLVE_WAVES * sl;
+            if (rp > r && rp < T) {
+                const double *Urr = U + (size_t)(16 * r) * mp + 16 * rp;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    double a = -Urr[(size_t)(4 * s + lg) * mp + lr];
+                    acc[sl] = mfma(a, b[s], acc[sl]);
+                }
+            }
+        }
+    }
+    if (is_y) {
+        // ||Z[:, 16cb:16cb+16]||_F^2, fixed reduction order
+        for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
+        if (lane == 0) zred[wave] = zz;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < SOLVE_WAVES; ++w) t += zred[w];
+            pl.zzpart[(size_t)u * 4 + cb] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// At = Z^T W  = (K^-1 Yu)^T  (the second triangular solve of dpotrs, gpy_linalg.py:139-148, as a product
+// with the explicit W).  Workgroup per column tile I of the unit, wave = 16-row block of At (Y columns).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_at(UnitTab ut, Pools pl) {
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int I = blockIdx.x;
+    if (I >= T) return;
+    int lane = threadIdx.x & 63, cbk = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *W = pl.W + ut.mat_off[u];
+    const double *Z = pl.Z + roff * YPAD;
+    double *At = pl.At + roff * YPAD;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = I; kt < T; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            size_t krow = (size_t)(16 * kt + 4 * s + lg);
+            double a = Z[krow * YPAD + 16 * cbk + lr];
+            double b = W[krow * mp + 16 * I + lr];
+            acc = mfma(a, b, acc);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) At[(size_t)(16 * cbk + lg + 4 * q) * mp + 16 * I + lr] = acc[q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient reduce.  Workgroup per (unit, column tile J); waves stride over row tiles I.  For each tile
+//   M_IJ = At_I^T At_J - dy * sum_{k >= max(I,J)} W_kI^T W_kJ          (MFMA, never stored)
+// and, by symmetry of M and k, the column sums give the rows of gradX for the 16 points of tile J:
+//   gX[j][d] = sum_i M[i][j] * dk(x_j, x_i)/dx_j[d]                       (gprf.py:556-573)
+//   gC partials: tr(M), sum M*k_noise_free, sum M*dk/dl_t                 (gprf.py:577-584, 362-375)
+// ------------------------------------------------------------------------------------------------
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256) void k_grad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
+    __shared__ double red[4][16][8];
+    __shared__ double gcred[4][8];
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int J = blockIdx.x;
+    if (J >= T) return;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *W = pl.W + ut.mat_off[u];
+    const double *At = pl.At + roff * YPAD;
+    const double *Xu = pl.Xu + roff * XPAD;
+    int j = 16 * J + lr;
+    double xj[XPAD];
+#pragma unroll
+    for (int d = 0; d < XPAD; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
+    int nks = (kp.dy + 3) >> 2;  // k-steps over the Y columns (rows of At); pad rows are zero
+    double dyd = (double)kp.dy;
+
+    double gx[3] = {0.0, 0.0, 0.0};
+    double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
+
+    for (int I = wave; I < T; I += 4) {
+        d4 accA = {0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < nks; ++s) {
+            size_t krow = (size_t)(4 * s + lg);
+            double a = At[krow * mp + 16 * I + lr];
+            double b = At[krow * mp + 16 * J + lr];
+            accA = mfma(a, b, accA);
+        }
+        d4 accP = {0.0, 0.0, 0.0, 0.0};
+        int k0 = (I > J) ? I : J;
+        for (int kt = k0; kt < T; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                size_t krow = (size_t)(16 * kt + 4 * s + lg);
+                double a = W[krow * mp + 16 * I + lr];
+                double b = W[krow * mp + 16 * J + lr];
+                accP = mfma(a, b, accP);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = 16 * I + lg + 4 * q;
+            if (i < m && j < m) {
+                double Mij = accA[q] - dyd * accP[q];
+                double xi[XPAD];
+#pragma unroll
+                for (int d = 0; d < XPAD; ++d) xi[d] = Xu[(size_t)i * XPAD + d];
+                double dkdx[3] = {0.0, 0.0, 0.0}, dkdl[3] = {0.0, 0.0, 0.0};
+                double k = KernFn<DIST, KERN>::full(kp, xi, xj, dkdx, dkdl);
+                if (i != j) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gx[d] += Mij * dkdx[d];
+                } else {
+                    gc_tr += Mij;
+                }
+                if (want_gc) {
+                    gc_sv += Mij * k;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
+                }
+            }
+        }
+    }
+    // column sums: over the 4 lane groups (rows lg + 4q), then over the 4 waves (row tiles)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        gx[d] += shfl_xor_d(gx[d], 16);
+        gx[d] += shfl_xor_d(gx[d], 32);
+    }
+    if (lg == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) red[wave][lr][d] = gx[d];
+    }
+    double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int jj = threadIdx.x >> 2, d = threadIdx.x & 3;
+        double v = 0.0;
+        if (d < 3) v = red[0][jj][d] + red[1][jj][d] + red[2][jj][d] + red[3][jj][d];
+        pl.gXu[(roff + 16 * J + jj) * XPAD + d] = v;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + GC_SLOTS) {
+        int t = threadIdx.x - 64;
+        double v = 0.0;
+        if (t < 5) v = gcred[0][t] + gcred[1][t] + gcred[2][t] + gcred[3][t];
+        pl.gcpart[((size_t)u * ut.max_T + J) * GC_SLOTS + t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Assembly (gprf.py:253-288): Bethe-weighted sums, deterministic gather (no float atomics).
+// block 0: ll and gradC; blocks >= 1: gradX, one thread per (point, coordinate).
+// out = [ll | gradX (n x dx) | gradC (2 + ndfn)]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
+                                                  int want_gx, int want_gc, double *out) {
+    int dx = kp.dx;
+    if (blockIdx.x == 0) {
+        __shared__ double red[256][6];
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int u = threadIdx.x; u < ut.n_units; u += 256) {
+            int m = ut.m[u];
+            double w = ut.weight[u];
+            if (m > 0) {
+                const double *zp = pl.zzpart + (size_t)u * 4;
+                double zz = (zp[0] + zp[1]) + (zp[2] + zp[3]);
+                double ll = -0.5 * zz - 0.5 * kp.dy * pl.logdet[u] -
+                            0.5 * kp.dy * m * 1.8378770664093454836 /* log 2pi */;
+                acc[0] += w * ll;
+                if (want_gc) {
+                    int T = pad16(m) >> 4;
+                    double g[5] = {0, 0, 0, 0, 0};
+                    for (int J = 0; J < T; ++J) {
+                        const double *gp = pl.gcpart + ((size_t)u * ut.max_T + J) * GC_SLOTS;
+                        for (int t = 0; t < 5; ++t) g[t] += gp[t];
+                    }
+                    acc[1] += w * 0.5 * g[0];             // d/d nv   : 1/2 tr(M)
+                    acc[2] += w * 0.5 * g[1] / kp.sv;     // d/d sv   : 1/2 sum M k / sv
+                    for (int t = 0; t < 3; ++t) acc[3 + t] += w * 0.5 * g[2 + t];
+                }
+            }
+        }
+        for (int t = 0; t < 6; ++t) red[threadIdx.x][t] = acc[t];
+        __syncthreads();
+        for (int s = 128; s >= 1; s >>= 1) {
+            if (threadIdx.x < s)
+                for (int t = 0; t < 6; ++t) red[threadIdx.x][t] += red[threadIdx.x + s][t];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out[0] = red[0][0];
+            int ncov = 2 + kp.ndfn;
+            double *gc = out + 1 + (size_t)n * dx;
+            for (int t = 0; t < ncov; ++t) gc[t] = want_gc ? red[0][1 + t] : 0.0;
+        }
+        return;
+    }
+    long idx = (long)(blockIdx.x - 1) * 256 + threadIdx.x;
+    if (idx >= (long)n * dx) return;
+    int p = (int)(idx / dx), d = (int)(idx % dx);
+    double v = 0.0;
+    if (want_gx) {
+        for (int64_t s = at.slot_ptr[p]; s < at.slot_ptr[p + 1]; ++s)
+            v += at.slot_w[s] * pl.gXu[(size_t)at.slot_row[s] * XPAD + d];
+    }
+    out[1 + idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
+    if (total_rows == 0) return;
+    hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);
+}
+
+void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s) {
+    if (total_rows == 0) return;
+    hipLaunchKernelGGL(k_gather_x, dim3((total_rows + 255) / 256), dim3(256), 0, s, ut.upt, X, p.Xu, dx, total_rows);
+}
+
+template <int D, int K>
+static void fill_t(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
+    int nt64 = (16 * ut.max_T + 63) / 64;
+    hipLaunchKernelGGL((k_fill<D, K>), dim3(nt64 * nt64, ut.n_units), dim3(256), 0, s, ut, p, kp, nt64);
+}
+
+void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
+    if (ut.n_units == 0 || ut.max_T == 0) return;
+    if (dist_id == 0 && kern_id == 0) fill_t<0, 0>(ut, p, kp, s);
+    else fill_t<1, 1>(ut, p, kp, s);
+}
+
+void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
+    if (ut.n_units == 0) return;
+    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256) * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_potrf, dim3(ut.n_units), dim3(POTRF_WAVES * 64), lds, s, ut, p);
+}
+
+void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
+    if (ut.n_units == 0) return;
+    hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_units), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
+}
+
+void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
+    if (ut.n_units == 0 || ut.max_T == 0) return;
+    hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_units), dim3(256), 0, s, ut, p);
+}
+
+void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
+                 hipStream_t s) {
+    if (ut.n_units == 0 || ut.max_T == 0) return;
+    dim3 grid(ut.max_T, ut.n_units);
+    if (dist_id == 0 && kern_id == 0)
+        hipLaunchKernelGGL((k_grad<0, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    else
+        hipLaunchKernelGGL((k_grad<1, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+}
+
+void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
+                     int want_gx, int want_gc, double *out, hipStream_t s) {
+    long work = (long)n * kp.dx;
+    int blocks = 1 + (int)((work + 255) / 256);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out);
+}
+
+}  // namespace gprf

@@ -1,0 +1,226 @@
+"""``GPRF`` — the reference's model object (``/root/reference/gprf.py:83-296``) over the MI355X HIP
+library.  Same constructor, same ``update_X / update_covs / llgrad`` surface and return shapes, so the
+reference's objective callbacks (gprfopt.py:377-417, run_seismic.py:121-199) drive it unchanged; the
+per-unit dense GP algebra (gprf.py:299-375, 496-591; gpy_linalg.py:77-253) runs in
+``libgprf_hip.so`` through the C ABI in ``include/gprf_hip.h``.
+
+There is no CPU path here: constructing a GPRF without the HIP library or a GPU raises.
+"""
+from collections import defaultdict
+
+import numpy as np
+
+from . import _capi
+from .cov import GPCov, SUPPORTED
+
+
+def symmetrize_neighbors(neighbors):
+    """gprf.py:76-81"""
+    nd = defaultdict(set)
+    for (i, j) in neighbors:
+        nd[i].add(j)
+        nd[j].add(i)
+    return nd
+
+
+def _csr_from_block_idxs(block_idxs):
+    lens = np.fromiter((len(b) for b in block_idxs), dtype=np.int64, count=len(block_idxs))
+    ptr = np.zeros(len(block_idxs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    if ptr[-1] > 0:
+        pts = np.concatenate([np.asarray(b, dtype=np.int32).ravel() for b in block_idxs]).astype(np.int32, copy=False)
+    else:
+        pts = np.zeros(0, dtype=np.int32)
+    return ptr, pts
+
+
+class GPRF(object):
+
+    def __init__(self, X, Y, block_fn, cov, noise_var, kernelized=False, dy=None,
+                 neighbor_threshold=1e-3, nonstationary=False, nonstationary_prec=False,
+                 block_idxs=None, neighbors=None, device=0, shard=None):
+        """Arguments as gprf.py:85-87.  ``kernelized`` / ``nonstationary`` are dead or broken branches in
+        the reference (Appendix A.9/11) and are refused.  ``device`` = HIP device
+        ordinal; ``shard`` = (rank, world) to evaluate only this rank's share of the units."""
+        if kernelized or nonstationary or nonstationary_prec:
+            raise NotImplementedError("kernelized / nonstationary GPRF variants are unreachable in the "
+                                      "reference (gprf.py:90-97,302) and are not provided")
+        if (cov.dfn_str, cov.wfn_str) not in SUPPORTED:
+            raise ValueError("unsupported covariance (%s, %s)" % (cov.dfn_str, cov.wfn_str))
+        if len(cov.wfn_params) != 1:
+            raise ValueError('gradient computation currently assumes just a single scaling parameter for '
+                             'weight function, but currently wfn_params=%s' % (cov.wfn_params,))  # gprf.py:369-370
+        self.X = X
+        self.kernelized = False
+        self.Y = Y
+        if block_idxs is None:
+            block_idxs = block_fn(X)
+        self.block_idxs = block_idxs
+        self.block_fn = block_fn
+        self.n_blocks = len(block_idxs)
+        self.nonstationary = False
+        self.cov = cov
+        self.noise_var = noise_var
+        self.neighbor_threshold = neighbor_threshold
+
+        n, dx = X.shape
+        self._ctx = _capi.Context(n, dx, Y.shape[1], _capi.DIST_IDS[cov.dfn_str], _capi.KERN_IDS[cov.wfn_str],
+                                  device=device)
+        if shard is not None:
+            self._ctx.set_shard(int(shard[0]), int(shard[1]))
+        self._ctx.set_Y(Y)
+        self._push_theta()
+        self._blocks_pushed = None
+        self._nbrs_pushed = None
+        self._jitter = None
+        self._push_blocks()
+
+        if neighbors is not None:
+            self.neighbors = neighbors
+        else:
+            self.compute_neighbors(threshold=neighbor_threshold)
+        self.compute_neighbor_count()
+        self.neighbor_dict = symmetrize_neighbors(self.neighbors)
+
+    # ------------------------------------------------------------------ state -> device
+    def _theta(self):
+        return np.concatenate([[self.noise_var, self.cov.wfn_params[0]],
+                               np.asarray(self.cov.dfn_params, dtype=np.float64).ravel()])
+
+    def _push_theta(self):
+        self._ctx.set_theta(self._theta())
+
+    def _push_blocks(self):
+        if self._blocks_pushed is self.block_idxs:
+            return
+        ptr, pts = _csr_from_block_idxs(self.block_idxs)
+        if len(ptr) - 1 != self.n_blocks:
+            raise ValueError("block_fn returned %d blocks, expected %d" % (len(ptr) - 1, self.n_blocks))
+        self._ctx.set_blocks(ptr, pts)
+        self._blocks_pushed = self.block_idxs
+        self._jitter = None
+        self._ctx.set_unit_jitter(None)
+
+    def _push_neighbors(self, neighbors):
+        if self._nbrs_pushed is neighbors:
+            return
+        self._ctx.set_neighbors(neighbors)
+        self._nbrs_pushed = neighbors
+        self._jitter = None
+        self._ctx.set_unit_jitter(None)
+
+    # ------------------------------------------------------------------ reference surface
+    def compute_neighbors(self, threshold=1e-3):
+        """gprf.py:119-150: connect blocks whose largest cross-covariance (relative to the signal
+        variance) exceeds ``threshold``; 1.0 means no pairs.  One-time setup, evaluated on the host with
+        the same kernel definitions."""
+        neighbors = []
+        if threshold == 1.0:
+            self.neighbors = neighbors
+            return
+        from .hostkernels import cross_kernel_max
+        for i in range(self.n_blocks):
+            X1 = self.X[self.block_idxs[i]]
+            for j in range(i):
+                X2 = self.X[self.block_idxs[j]]
+                if len(X1) == 0 or len(X2) == 0:
+                    continue
+                if cross_kernel_max(X1, X2, self.cov) > threshold:
+                    neighbors.append((i, j))
+        self.neighbors = neighbors
+
+    def compute_neighbor_count(self):
+        """gprf.py:152-157"""
+        neighbor_count = defaultdict(int)
+        for (i, j) in self.neighbors:
+            neighbor_count[i] += 1
+            neighbor_count[j] += 1
+        self.neighbor_count = neighbor_count
+
+    def update_covs(self, covs):
+        """gprf.py:160-167: covs[0] = [noise_var, signal_var, lengthscales...]"""
+        nv, sv = covs[0, :2]
+        lscales = covs[0, 2:]
+        self.cov = GPCov(wfn_params=[sv, ], dfn_params=lscales, dfn_str=self.cov.dfn_str, wfn_str=self.cov.wfn_str)
+        self.noise_var = nv
+        self._push_theta()
+
+    def update_X(self, new_X, update_blocks=True, recompute_neighbors=False):
+        """gprf.py:169-174: rebinding X re-runs block_fn on every call; the neighbour list stays."""
+        self.X = new_X
+        if self.block_fn is not None:
+            self.block_idxs = self.block_fn(new_X)
+            self._push_blocks()
+        if recompute_neighbors:
+            self.compute_neighbors(threshold=self.neighbor_threshold)
+            self.compute_neighbor_count()
+            self.neighbor_dict = symmetrize_neighbors(self.neighbors)
+
+    def update_X_block(self, i, new_X):
+        """gprf.py:176-179"""
+        self.X[self.block_idxs[i]] = new_X
+
+    def llgrad(self, parallel=False, local=True, grad_X=False, grad_cov=False, **kwargs):
+        """gprf.py:206-296 -> (ll, gradX (n,dx) or (0,0), gradCov (1,ncov) or (0,0)).
+
+        ``parallel`` (a multiprocessing pool over units in the reference, gprf.py:218-233) is accepted and
+        ignored: every unit already runs concurrently on the GPU.  ``local=False`` = all block pairs
+        (gprf.py:214-216)."""
+        if kwargs:
+            raise TypeError("unsupported llgrad arguments: %s" % sorted(kwargs))
+        self._push_blocks()
+        if self._jitter is not None:
+            # every reference call starts un-jittered (jitchol is stateless, gpy_linalg.py:77-80)
+            self._jitter = None
+            self._ctx.set_unit_jitter(None)
+        if local:
+            neighbors = self.neighbors
+        else:
+            if getattr(self, "_all_pairs_nb", None) != self.n_blocks:
+                self._all_pairs = [(i, j) for i in range(self.n_blocks) for j in range(i)]
+                self._all_pairs_nb = self.n_blocks
+            neighbors = self._all_pairs
+        self._push_neighbors(neighbors)
+
+        X = np.ascontiguousarray(self.X, dtype=np.float64)
+        rc, ll, gX, gC, bad = self._ctx.eval(X, grad_X, grad_cov)
+        if rc == _capi.GPRF_NOT_PD:
+            rc, ll, gX, gC = self._retry_with_jitter(X, grad_X, grad_cov, bad)
+
+        gradX = gX if grad_X else np.zeros((0, 0))
+        gradCov = gC.reshape((1, -1)) if grad_cov else np.zeros((0, 0))
+        return ll, gradX, gradCov
+
+    def _retry_with_jitter(self, X, grad_X, grad_cov, bad):
+        """jitchol's policy (gpy_linalg.py:81-97) applied per failing unit: require a positive diagonal,
+        then retry on K + j I with j = mean(diag K) * 1e-6 * 10^k, k = 0..4; the factor of the jittered
+        matrix is then used for everything.  diag K = sv + nv for both kernels."""
+        n_units = self.n_blocks + len(self._nbrs_pushed)
+        diag_mean = self.cov.wfn_params[0] + self.noise_var
+        if not (diag_mean > 0.):
+            raise _capi.NotPositiveDefinite("not pd: non-positive diagonal elements", bad)
+        jitter = np.zeros(n_units) if self._jitter is None else self._jitter.copy()
+        tries = defaultdict(int)
+        while True:
+            k = tries[bad]
+            if k >= 5:
+                raise _capi.NotPositiveDefinite("not positive definite, even with jitter.", bad)
+            jitter[bad] = diag_mean * 1e-6 * 10.0 ** k
+            tries[bad] += 1
+            self._ctx.set_unit_jitter(jitter)
+            self._jitter = jitter
+            rc, ll, gX, gC, bad = self._ctx.eval(X, grad_X, grad_cov)
+            if rc == _capi.GPRF_OK:
+                return rc, ll, gX, gC
+
+    # reference attribute names some callers read
+    @property
+    def n_units(self):
+        return self._ctx.num_units()[0]
+
+    def close(self):
+        self._ctx.close()
+
+    def __getstate__(self):
+        raise TypeError("GPRF holds device state and is not picklable (the reference pickles it only for "
+                        "its multiprocessing pool, gprf.py:738-746, which this build does not use)")

@@ -1,0 +1,128 @@
+/*
+ * gprf_hip.h — C ABI of libgprf_hip.so: the MI355X (gfx950) implementation of the GPRF block-local
+ * log-likelihood + gradient path of davmre/gprf.
+ *
+ * Boundary: everything from "blocks + neighbour pairs + X + Y + hypers" down to
+ * "(ll, gradX, gradCov)" — i.e. what the reference computes in
+ *     GPRF.llgrad            /root/reference/gprf.py:206-296
+ *     GPRF.llgrad_unary      gprf.py:299-308
+ *     GPRF.llgrad_joint      gprf.py:310-330
+ *     GPRF.gaussian_llgrad   gprf.py:496-591
+ *     GPRF.kernel/dKdx/dKdi  gprf.py:333-375   (treegp VectorTree.kernel_matrix /
+ *                                                kernel_deriv_wrt_xi_row / kernel_deriv_wrt_i)
+ *     pdinv / jitchol / dpotrs   /root/reference/gpy_linalg.py:77-97, 139-148, 219-240
+ * is one call, gprf_eval().  The Python object above it (gprf_amd/gprf.py) keeps the reference's
+ * GPRF surface; INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions: all matrices are row-major (C order) float64, exactly the numpy arrays the reference
+ * holds; index arrays are int32/int64 as stated; every function returns an int status:
+ *     0  GPRF_OK
+ *     1  GPRF_NOT_PD     some unit's kernel matrix is not positive definite (jitchol would retry;
+ *                        gpy_linalg.py:77-97) — *first_bad_unit says which; outputs are undefined
+ *    <0  a HIP / argument error; gprf_last_error() has the text
+ * No callbacks, no global state; host pointers are borrowed for the duration of the call only.
+ * One context is bound to one device and one stream; calls on one context must not overlap.
+ */
+#ifndef GPRF_HIP_H
+#define GPRF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gprf_ctx gprf_ctx;
+
+#define GPRF_OK 0
+#define GPRF_NOT_PD 1
+#define GPRF_ERR_ARG (-1)
+#define GPRF_ERR_HIP (-2)
+#define GPRF_ERR_STATE (-3)
+
+/* dfn_str / wfn_str of treegp's GPCov (gprf.py:109,163; run_seismic.py:299-301) */
+#define GPRF_DIST_EUCLIDEAN 0 /* "euclidean": r^2 = sum_d ((x_d - x'_d)/l_d)^2, one l per input dim */
+#define GPRF_DIST_LLD 1       /* "lld": (lon deg, lat deg, depth km), haversine km / l_0, ddepth / l_1 */
+#define GPRF_KERN_SE 0        /* "se":       k = sv * exp(-r^2)   (no 1/2 factor) */
+#define GPRF_KERN_MATERN32 1  /* "matern32": k = sv * (1 + sqrt3 r) exp(-sqrt3 r) */
+
+/* Largest unit (block, or concatenated block pair) the kernels accept, in points. */
+#define GPRF_MAX_UNIT 512
+
+/* Replaces GPRF.__init__ (gprf.py:85-117) + the VectorTree construction (gprf.py:109).
+ * n points, dx input dims (2 or 3), dy output columns; device = HIP device ordinal. */
+int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
+                int32_t device);
+int gprf_destroy(gprf_ctx *ctx);
+const char *gprf_last_error(const gprf_ctx *ctx);
+
+/* self.Y (gprf.py:97): n x dy, uploaded once and kept resident in HBM. */
+int gprf_set_Y(gprf_ctx *ctx, const double *Y);
+
+/* update_covs (gprf.py:160-167): theta = [noise_var, signal_var, dfn_params...], ntheta = 2 + #dfn_params
+ * (euclidean: dx lengthscales; lld: 2). */
+int gprf_set_theta(gprf_ctx *ctx, const double *theta, int32_t ntheta);
+
+/* self.block_idxs (gprf.py:100,172): CSR form of the list of index arrays; block b owns
+ * point_idx[block_ptr[b] .. block_ptr[b+1]).  Order inside a block is kept (it fixes the row order of
+ * the unit matrices, gprf.py:301,317-326).  Blocks may be empty (gprf.py:507-513). */
+int gprf_set_blocks(gprf_ctx *ctx, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx);
+
+/* self.neighbors (gprf.py:112,212): n_pairs rows (i, j); each becomes one joint unit with block i's rows
+ * first (gprf.py:322).  Bethe weights 1 - deg(i) for the unaries are derived here
+ * (compute_neighbor_count gprf.py:152-157; llgrad gprf.py:253-254, 264, 287).  For local=False pass all
+ * pairs (gprf.py:214-216). */
+int gprf_set_neighbors(gprf_ctx *ctx, int32_t n_pairs, const int32_t *pairs_ij);
+
+/* Unit-sharding for one-process-per-GPU runs: this context evaluates only the units that the
+ * longest-processing-time partition over `world` ranks gives to `rank`; gprf_eval then returns that
+ * rank's partial sums (to be all-reduced by the caller).  Default (0, 1) = everything. */
+int gprf_set_shard(gprf_ctx *ctx, int32_t rank, int32_t world);
+
+/* jitchol's retry (gpy_linalg.py:86-96): extra diagonal added to unit `u`'s kernel matrix.
+ * Units are numbered: blocks 0..n_blocks-1, then pairs in the order given.  NULL clears all. */
+int gprf_set_unit_jitter(gprf_ctx *ctx, int32_t n_units, const double *jitter);
+
+/* One objective+gradient evaluation = GPRF.llgrad(local=True, grad_X=, grad_cov=) at self.X = X
+ * (gprf.py:206-296).  X: n x dx (host).  ll_out: 1 double.  gradX_out: n x dx, fully overwritten (NULL if
+ * !want_gradX).  gradC_out: ntheta doubles in theta order (NULL if !want_gradC).
+ * first_bad_unit: set to the lowest failing unit id when GPRF_NOT_PD is returned, else -1. */
+int gprf_eval(gprf_ctx *ctx, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
+              double *gradX_out, double *gradC_out, int32_t *first_bad_unit);
+
+/* Same evaluation with device-resident input and output (the timed form; also what a multi-GPU caller
+ * all-reduces).  d_X: n*dx doubles in HBM.  d_out: 1 + n*dx + ntheta doubles in HBM laid out
+ * [ll | gradX row-major | gradC]; gradX / gradC parts are zero-filled when not requested.
+ * stream: a hipStream_t (NULL = the context's own stream); the call only enqueues work.
+ * Follow with gprf_eval_status() after synchronising the stream. */
+int gprf_eval_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX, int32_t want_gradC,
+                     double *d_out, void *stream);
+/* Blocks until the context's last evaluation has finished; returns GPRF_OK / GPRF_NOT_PD as gprf_eval. */
+int gprf_eval_status(gprf_ctx *ctx, int32_t *first_bad_unit);
+
+/* Bookkeeping a caller may want. */
+int gprf_num_units(const gprf_ctx *ctx, int32_t *n_units_total, int32_t *n_units_local);
+/* sum over local units of the algorithmic work of SURVEY.md §8d: flops = m^3 + 4 m^2 dy,
+ * fill bytes = 8 m^2. */
+int gprf_work_estimate(gprf_ctx *ctx, double *flops, double *fill_bytes);
+
+/* HIP-event timing of the kernels of the most recent gprf_eval*/
+/* names: "gather","fill","potrf","solve","at","grad","assemble"; ms_out[i] = that kernel's duration in
+ * the last evaluation made while timing was enabled (gprf_set_timing(ctx, 1)). */
+int gprf_set_timing(gprf_ctx *ctx, int32_t enable);
+int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
+#define GPRF_N_STAGES 7
+
+/* Per-stage parity hooks (tests only): after an evaluation, copy one local unit's intermediates to the
+ * host.  what: 0 K-fill/U (mp x mp, upper triangle = Cholesky factor U, K = U^T U, after potrf),
+ * 1 W = U^-T (mp x mp, lower), 2 Z = U^-T Y (mp x 64), 3 At = (K^-1 Y)^T (64 x mp),
+ * 4 per-row gradient slab (mp x 4), 5 [ll_u, logdet_u, zz_u, info_u].  mp = m rounded up to 16.
+ * `stop_after` for gprf_debug_run: run the pipeline only up to a stage (0 = fill only ... 6 = all). */
+int gprf_debug_run(gprf_ctx *ctx, const double *X, int32_t stop_after);
+int gprf_debug_fetch(gprf_ctx *ctx, int32_t local_unit, int32_t what, double *out, int64_t out_len);
+int gprf_debug_unit_shape(gprf_ctx *ctx, int32_t local_unit, int32_t *m, int32_t *mp, int32_t *global_unit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRF_HIP_H */
