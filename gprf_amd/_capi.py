@@ -32,6 +32,7 @@ SIGNATURES = {
     "gprf_set_blocks": (ctypes.c_int, [_vp, _i32, _i64p, _i32p]),
     "gprf_set_neighbors": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
+    "gprf_partition_units": (ctypes.c_int, [_i32, _i32p, _i32, _i32, _i32p]),
     "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_eval": (ctypes.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, _dp, _i32p]),
     "gprf_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
@@ -82,6 +83,16 @@ def load(build_if_missing=True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def partition_units(m, dy, world):
+    """owner rank of every unit (gprf_partition_units; host only, no GPU needed)."""
+    m = np.ascontiguousarray(m, dtype=np.int32)
+    owner = np.zeros(len(m), dtype=np.int32)
+    rc = load().gprf_partition_units(len(m), m.ctypes.data_as(_i32p), int(dy), int(world), owner.ctypes.data_as(_i32p))
+    if rc != GPRF_OK:
+        raise GprfHipError("gprf_partition_units failed (%d)" % rc)
+    return owner
 
 
 def dptr(a):
@@ -182,13 +193,16 @@ class Context(object):
         self._check(self.lib.gprf_work_estimate(self.h, ctypes.byref(f), ctypes.byref(b)), "gprf_work_estimate")
         return f.value, b.value
 
-    def set_timing(self, on):
-        self._check(self.lib.gprf_set_timing(self.h, 1 if on else 0), "gprf_set_timing")
+    def set_timing(self, on, reset=False):
+        self._check(self.lib.gprf_set_timing(self.h, 2 if (on and reset) else (1 if on else 0)), "gprf_set_timing")
 
     def get_timing(self):
-        ms = np.zeros(N_STAGES)
-        self._check(self.lib.gprf_get_timing(self.h, N_STAGES, dptr(ms)), "gprf_get_timing")
-        return dict(zip(STAGE_NAMES, ms.tolist()))
+        """average ms per stage over the evaluations timed since the last reset, plus 'count'"""
+        ms = np.zeros(2 * N_STAGES + 1)
+        self._check(self.lib.gprf_get_timing(self.h, len(ms), dptr(ms)), "gprf_get_timing")
+        d = dict(zip(STAGE_NAMES, ms[:N_STAGES].tolist()))
+        d["count"] = int(ms[2 * N_STAGES])
+        return d
 
     # ---- per-stage parity hooks (tests) ----
     def debug_run(self, X, stop_after=6):

@@ -92,10 +92,17 @@ struct gprf_ctx {
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
 
-    // timing
+    // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
+    // a slot's elapsed times are folded into the running totals when the slot is about to be reused
+    static constexpr int RING = 32;
     bool timing = false;
-    hipEvent_t ev[GPRF_N_STAGES + 1] = {};
+    hipEvent_t ev[RING][GPRF_N_STAGES + 1] = {};
     bool ev_valid = false;
+    bool slot_pending[RING] = {};
+    uint64_t n_timed = 0;          // evaluations recorded
+    uint64_t n_folded = 0;         // evaluations folded into stage_ms_sum
+    double stage_ms_sum[GPRF_N_STAGES] = {};
+    double stage_ms_last[GPRF_N_STAGES] = {};
     bool eval_pending = false;
 };
 
@@ -152,7 +159,8 @@ KParams make_kparams(gprf_ctx *c) {
 int rebuild_units(gprf_ctx *c) {
     const int nb = c->n_blocks, np = c->n_pairs;
     const int nu = nb + np;
-    std::vector<int> um(nu), deg(nb, 0);
+    std::vector<int32_t> um(nu);
+    std::vector<int> deg(nb, 0);
     for (int b = 0; b < nb; ++b) um[b] = (int)(c->block_ptr[b + 1] - c->block_ptr[b]);
     for (int q = 0; q < np; ++q) {
         int i = c->pairs[2 * q], j = c->pairs[2 * q + 1];
@@ -171,20 +179,7 @@ int rebuild_units(gprf_ctx *c) {
         }
     // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy
     std::vector<int> owner(nu, 0);
-    if (c->world > 1) {
-        std::vector<int> order(nu);
-        std::iota(order.begin(), order.end(), 0);
-        auto cost = [&](int u) { double m = um[u]; return m * m * m + 4.0 * m * m * c->dy; };
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
-        std::vector<double> load(c->world, 0.0);
-        for (int u : order) {
-            int best = 0;
-            for (int r = 1; r < c->world; ++r)
-                if (load[r] < load[best]) best = r;
-            owner[u] = best;
-            load[best] += cost(u);
-        }
-    }
+    if (c->world > 1 && nu > 0) gprf_partition_units(nu, um.data(), c->dy, c->world, owner.data());
     c->l_global.clear(); c->l_m.clear(); c->l_rowoff.clear(); c->l_matoff.clear();
     std::vector<double> weight, jitter;
     long rows = 0;
@@ -310,6 +305,20 @@ int check_ready(gprf_ctx *c) {
     return GPRF_OK;
 }
 
+// fold one finished event slot into the running per-stage totals (waits for the slot's last event)
+int fold_slot(gprf_ctx *c, int slot) {
+    HIP_TRY(c, hipEventSynchronize(c->ev[slot][GPRF_N_STAGES]));
+    for (int i = 0; i < GPRF_N_STAGES; ++i) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[slot][i], c->ev[slot][i + 1]));
+        c->stage_ms_sum[i] += ms;
+        c->stage_ms_last[i] = ms;
+    }
+    c->n_folded++;
+    c->slot_pending[slot] = false;
+    return GPRF_OK;
+}
+
 // enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug)
 int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
                  int stop_after) {
@@ -323,11 +332,21 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     AssembleTab at{c->d_slot_ptr.p, c->d_slot_row.p, c->d_slot_w.p};
     bool tm = c->timing;
     if (tm && !c->ev_valid) {
-        for (int i = 0; i <= GPRF_N_STAGES; ++i) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+        for (int r = 0; r < gprf_ctx::RING; ++r)
+            for (int i = 0; i <= GPRF_N_STAGES; ++i) HIP_TRY(c, hipEventCreate(&c->ev[r][i]));
         c->ev_valid = true;
     }
+    int slot = (int)(c->n_timed % gprf_ctx::RING);
+    if (tm) {
+        if (c->slot_pending[slot]) {
+            int rc = fold_slot(c, slot);
+            if (rc != GPRF_OK) return rc;
+        }
+        c->slot_pending[slot] = true;
+        c->n_timed++;
+    }
     int stage = 0;
-    auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[stage], s); ++stage; };
+    auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[slot][stage], s); ++stage; };
     mark();
     launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
     mark();
@@ -413,7 +432,8 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
     c->d_gcpart.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
     if (c->ev_valid)
-        for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int r = 0; r < gprf_ctx::RING; ++r)
+            for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;
@@ -470,6 +490,23 @@ int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
     c->n_pairs = n_pairs;
     c->pairs.assign(pairs_ij, pairs_ij + 2 * (size_t)n_pairs);
     c->units_dirty = true;
+    return GPRF_OK;
+}
+
+int gprf_partition_units(int32_t n_units, const int32_t *m, int32_t dy, int32_t world, int32_t *owner_out) {
+    if (n_units < 0 || world < 1 || (n_units > 0 && (!m || !owner_out))) return GPRF_ERR_ARG;
+    std::vector<int> order(n_units);
+    std::iota(order.begin(), order.end(), 0);
+    auto cost = [&](int u) { double mm = m[u]; return mm * mm * mm + 4.0 * mm * mm * dy; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<double> load(world, 0.0);
+    for (int u : order) {
+        int best = 0;
+        for (int r = 1; r < world; ++r)
+            if (load[r] < load[best]) best = r;
+        owner_out[u] = best;
+        load[best] += cost(u);
+    }
     return GPRF_OK;
 }
 
@@ -552,18 +589,28 @@ int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
 int gprf_set_timing(gprf_ctx *c, int32_t enable) {
     if (!c) return GPRF_ERR_ARG;
     c->timing = enable != 0;
+    if (enable == 2) {  // reset the running totals
+        if (c->ev_valid) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            for (int r = 0; r < gprf_ctx::RING; ++r)
+                if (c->slot_pending[r]) { int rc = fold_slot(c, r); if (rc != GPRF_OK) return rc; }
+        }
+        c->n_timed = c->n_folded = 0;
+        for (int i = 0; i < GPRF_N_STAGES; ++i) c->stage_ms_sum[i] = c->stage_ms_last[i] = 0.0;
+    }
     return GPRF_OK;
 }
 
 int gprf_get_timing(gprf_ctx *c, int32_t n, double *ms_out) {
     if (!c || !ms_out || n < GPRF_N_STAGES) return GPRF_ERR_ARG;
-    if (!c->ev_valid) return fail(c, GPRF_ERR_STATE, "no timed evaluation yet");
+    if (!c->ev_valid || c->n_timed == 0) return fail(c, GPRF_ERR_STATE, "no timed evaluation yet");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventSynchronize(c->ev[GPRF_N_STAGES]));
-    for (int i = 0; i < GPRF_N_STAGES; ++i) {
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-        ms_out[i] = ms;
+    for (int r = 0; r < gprf_ctx::RING; ++r)
+        if (c->slot_pending[r]) { int rc = fold_slot(c, r); if (rc != GPRF_OK) return rc; }
+    for (int i = 0; i < GPRF_N_STAGES; ++i) ms_out[i] = c->stage_ms_sum[i] / (double)c->n_folded;
+    if (n >= 2 * GPRF_N_STAGES + 1) {
+        for (int i = 0; i < GPRF_N_STAGES; ++i) ms_out[GPRF_N_STAGES + i] = c->stage_ms_last[i];
+        ms_out[2 * GPRF_N_STAGES] = (double)c->n_folded;
     }
     return GPRF_OK;
 }

@@ -1,0 +1,120 @@
+"""Synthetic benchmark inputs with the reference's recipe (seeds, shapes, RNG stream):
+``synthetic.sample_synthetic`` / ``sample_y`` (synthetic.py:103-114, 139-153) and
+``gprfopt.SampledData`` (gprfopt.py:19-74, 172-182).  Not part of the accelerated path; it only
+defines what the path is fed.  The N x N prior Cholesky may run on the GPU through torch (plumbing).
+"""
+import os
+
+import numpy as np
+
+from .blocking import Blocker
+from .cov import GPCov
+from . import hostkernels
+
+
+def _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu):
+    n = X.shape[0]
+    if use_gpu:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        Xd = torch.as_tensor(X, dtype=torch.float64, device=dev)
+        ls = torch.as_tensor(np.asarray(cov.dfn_params, dtype=np.float64), device=dev)
+        K = torch.empty((n, n), dtype=torch.float64, device=dev)
+        step = 4096
+        for s in range(0, n, step):
+            diff = (Xd[s:s + step, None, :] - Xd[None, :, :]) / ls
+            d = torch.sqrt((diff * diff).sum(dim=2))
+            K[s:s + step] = cov.wfn_params[0] * torch.exp(-1.0 * d * d)
+            del diff, d
+        K.diagonal().add_(noise_var)
+        L = torch.linalg.cholesky(K)
+        del K
+        Y = (L @ torch.as_tensor(Z, dtype=torch.float64, device=dev)).cpu().numpy()
+        del L
+        torch.cuda.empty_cache()
+        return Y
+    from scipy.linalg import lapack
+    K = np.empty((n, n))
+    step = 2048
+    for s in range(0, n, step):
+        K[s:s + step] = hostkernels.kernel_matrix(X[s:s + step], X, cov)
+    K[np.diag_indices(n)] += noise_var
+    L, info = lapack.dpotrf(K, lower=1, overwrite_a=1)
+    if info != 0:
+        raise np.linalg.LinAlgError("prior covariance not positive definite")
+    return np.dot(L, Z)
+
+
+def sample_synthetic(seed=1, n=400, xd=2, yd=10, lscale=0.1, noise_var=0.01, use_gpu=False):
+    """synthetic.py:139-153 (seed < 1000): X ~ U[0,1]^xd, Y = chol(K + nv I) Z with Z drawn from the same
+    RNG stream right after X (no reseed).  Dense only (the reference switches to a sparse CHOLMOD
+    approximation at n >= 40000, synthetic.py:106, which is not reproduced)."""
+    np.random.seed(seed)
+    X = np.random.rand(n, xd)
+    cov = GPCov(wfn_params=[1.0], dfn_params=[lscale] * xd, dfn_str="euclidean", wfn_str="se")
+    Z = np.random.randn(n, yd)
+    Y = _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu)
+    return X, Y, cov
+
+
+class SampledData(object):
+    """gprfopt.py:19-74, 172-182."""
+
+    def __init__(self, noise_var=0.01, n=30, ntrain=20, lscale=0.5, obs_std=0.05, yd=10, seed=1, use_gpu=False,
+                 cache_dir=None):
+        self.noise_var, self.n, self.ntrain, self.lscale = noise_var, n, ntrain, lscale
+        Xfull = Yfull = None
+        cache = None
+        if cache_dir is not None:
+            os.makedirs(cache_dir, exist_ok=True)
+            cache = os.path.join(cache_dir, "%d_%d_%.6f_%d_%d_%.4f.npz" % (n, ntrain, lscale, yd, seed, noise_var))
+            if os.path.exists(cache):
+                z = np.load(cache)
+                Xfull, Yfull = z["X"], z["Y"]
+                cov = GPCov(wfn_params=[1.0], dfn_params=[lscale, lscale], dfn_str="euclidean", wfn_str="se")
+        if Xfull is None:
+            Xfull, Yfull, cov = sample_synthetic(n=n, noise_var=noise_var, yd=yd, lscale=lscale, seed=seed,
+                                                 use_gpu=use_gpu)
+            if cache is not None:
+                np.savez(cache, X=Xfull, Y=Yfull)
+        self.cov = cov
+        self.SX, self.SY = Xfull[:ntrain, :], np.ascontiguousarray(Yfull[:ntrain, :])
+        self.Xtest, self.Ytest = Xfull[ntrain:, :], Yfull[ntrain:, :]
+        self.block_idxs = None
+        self.obs_std = obs_std
+        np.random.seed(seed)
+        self.X_obs = self.SX + np.random.randn(*self.SX.shape) * obs_std
+
+    def set_centers(self, centers):
+        """gprfopt.py:41-46"""
+        self.centers = np.asarray(centers)
+        b = Blocker(self.centers)
+        self.blocker = b
+        self.block_idxs = b.block_clusters(self.X_obs)
+        self.reblock = lambda X: b.block_clusters(X)
+        self.neighbors = b.neighbors(diag_connections=True)
+
+    def build_gprf(self, X=None, cov=None, local_dist=1e-4, **kw):
+        """gprfopt.py:55-74: neighbours are used iff local_dist < 1.0."""
+        from .gprf import GPRF
+        if X is None:
+            X = self.X_obs
+        if cov is None:
+            cov, noise_var = self.cov, self.noise_var
+        elif cov.shape[0] == 1:
+            noise_var = cov[0, 0]
+            cov = GPCov(wfn_params=[cov[0, 1]], dfn_params=cov[0, 2:], dfn_str="euclidean", wfn_str="se")
+        else:
+            raise Exception("invalid cov params %s" % (cov,))
+        return GPRF(X, Y=self.SY, block_fn=self.reblock, block_idxs=self.block_idxs, cov=cov, noise_var=noise_var,
+                    kernelized=False, neighbor_threshold=local_dist,
+                    neighbors=self.neighbors if local_dist < 1.0 else [], **kw)
+
+    def x_prior(self, xx):
+        """gprfopt.py:172-182"""
+        flatobs = self.X_obs.flatten()
+        n = len(xx)
+        r = (xx - flatobs) / self.obs_std
+        ll = -.5 * np.sum(r ** 2) - .5 * n * np.log(2 * np.pi * self.obs_std ** 2)
+        lderiv = -(xx - flatobs) / (self.obs_std ** 2)
+        return ll, lderiv

@@ -79,6 +79,11 @@ int gprf_set_neighbors(gprf_ctx *ctx, int32_t n_pairs, const int32_t *pairs_ij);
  * rank's partial sums (to be all-reduced by the caller).  Default (0, 1) = everything. */
 int gprf_set_shard(gprf_ctx *ctx, int32_t rank, int32_t world);
 
+/* The partition gprf_set_shard uses, exposed so that callers / tests can inspect it without a GPU:
+ * unit u has m[u] points; owner_out[u] = rank that evaluates it.  Greedy longest-processing-time-first
+ * on cost m^3 + 4 m^2 dy, ties to the lowest rank, stable in u.  Pure host code. */
+int gprf_partition_units(int32_t n_units, const int32_t *m, int32_t dy, int32_t world, int32_t *owner_out);
+
 /* jitchol's retry (gpy_linalg.py:86-96): extra diagonal added to unit `u`'s kernel matrix.
  * Units are numbered: blocks 0..n_blocks-1, then pairs in the order given.  NULL clears all. */
 int gprf_set_unit_jitter(gprf_ctx *ctx, int32_t n_units, const double *jitter);
@@ -106,9 +111,12 @@ int gprf_num_units(const gprf_ctx *ctx, int32_t *n_units_total, int32_t *n_units
  * fill bytes = 8 m^2. */
 int gprf_work_estimate(gprf_ctx *ctx, double *flops, double *fill_bytes);
 
-/* HIP-event timing of the kernels of the most recent gprf_eval*/
-/* names: "gather","fill","potrf","solve","at","grad","assemble"; ms_out[i] = that kernel's duration in
- * the last evaluation made while timing was enabled (gprf_set_timing(ctx, 1)). */
+/* HIP-event timing of the kernels, recorded on the stream the evaluation is enqueued on.
+ * Stages: "gather","fill","potrf","solve","at","grad","assemble".  gprf_set_timing(ctx, 1) turns recording
+ * on (events between every kernel of every evaluation, kept in a ring so back-to-back evaluations need no
+ * host sync), 0 off, 2 = on + reset the running totals.  gprf_get_timing waits for outstanding
+ * evaluations and returns ms_out[0..6] = average duration per stage over the evaluations recorded since
+ * the reset; if n >= 15 also ms_out[7..13] = the last evaluation's durations and ms_out[14] = the count. */
 int gprf_set_timing(gprf_ctx *ctx, int32_t enable);
 int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
 #define GPRF_N_STAGES 7

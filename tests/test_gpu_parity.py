@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI / gprf_amd.GPRF) against the oracle and the committed golden
+vectors.  Floating point (fp64) throughout; tolerances are stated per test.  North-star tolerance:
+gradient max-abs error < 1e-8 on the n=10000 configuration (tests/test_gpu_northstar.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, blocks_from_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _gprf_from_golden(z, suffix="", dfn="euclidean", wfn="se", Xkey="X", Ykey="Y", nbrs=None, **kw):
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov
+    th = z["theta"]
+    blocks = blocks_from_csr(z["block_ptr"], z["block_pts"])
+    if nbrs is None:
+        nbrs = [tuple(int(v) for v in r) for r in z["neighbors"]]
+    return GPRF(z[Xkey], z[Ykey], None, GPCov([th[1]], th[2:], dfn, wfn), th[0], block_idxs=blocks, neighbors=nbrs, **kw)
+
+
+def _close(gpu, ref, rtol):
+    """max-abs error relative to the largest reference magnitude"""
+    scale = max(np.max(np.abs(ref)), 1e-300)
+    return np.max(np.abs(gpu - ref)) <= rtol * scale
+
+
+def test_library_loaded_is_hip():
+    """The .so this process uses is the in-tree HIP library and it sees the GPU."""
+    from gprf_amd import _capi
+    lib = _capi.load()
+    assert "libgprf_hip.so" in _capi.library_path()
+    ctx = _capi.Context(8, 2, 3, 0, 0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["local", "gprf"])
+def test_c1_against_golden(tag):
+    """BASELINE config 1 (ntrain=500, 4 blocks, yd=10, lscale=0.4): ll rel 1e-12, gradients rel 1e-10 of max."""
+    z = load_golden("c1_small.npz")
+    nbrs = [] if tag == "local" else None
+    g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY", nbrs=nbrs)
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(ll, z["ll_" + tag], rtol=1e-12)
+    assert gX.shape == (500, 2) and gC.shape == (1, 4)
+    assert _close(gX, z["gX_" + tag], 1e-10)
+    assert np.allclose(gC, z["gC_" + tag], rtol=1e-9)
+    # no-gradient call returns the reference's empty arrays (gprf.py:275,291)
+    ll2, e1, e2 = g.llgrad()
+    assert ll2 == ll and e1.shape == (0, 0) and e2.shape == (0, 0)
+    g.close()
+
+
+def test_c1_all_pairs_local_false():
+    """local=False = every block pair, Bethe weight 1-(nb-1) (gprf.py:214-216)."""
+    z = load_golden("c1_small.npz")
+    g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY")
+    ll, gX, _ = g.llgrad(local=False, grad_X=True)
+    assert np.isclose(ll, z["ll_allpairs"], rtol=1e-12)
+    assert _close(gX, z["gX_allpairs"], 1e-10)
+    ll3, _, _ = g.llgrad(local=True)       # and back
+    assert np.isclose(ll3, z["ll_gprf"], rtol=1e-12)
+    g.close()
+
+
+def test_tiny_per_stage_matrices():
+    """Stage-level parity on the pair unit of the tiny case: Cholesky factor, inverse (as W^T W), Alpha."""
+    z = load_golden("tiny_parts.npz")
+    g = _gprf_from_golden(z)
+    ctx = g._ctx
+    g._push_neighbors(g.neighbors)
+    ctx.debug_run(z["X"], 6)
+    l = 2                                   # units: block 0, block 1, pair (1,0)
+    m, mp, gu = ctx.debug_unit_shape(l)
+    assert (m, mp, gu) == (60, 64, 2)
+    U = np.triu(ctx.debug_fetch(l, 0)[:m, :m])
+    assert np.allclose(U.T, z["pair_L"], rtol=0, atol=1e-13)            # K = U^T U, U^T = LAPACK's L
+    Ufull = ctx.debug_fetch(l, 0)
+    assert np.array_equal(np.triu(Ufull[m:, m:]), np.eye(mp - m))       # identity padding
+    W = np.tril(ctx.debug_fetch(l, 1)[:m, :m])
+    assert _close(W.T @ W, z["pair_prec"], 1e-12)
+    At = ctx.debug_fetch(l, 3)
+    assert _close(At[:7, :m].T, z["pair_Alpha"], 1e-12)
+    assert np.all(At[7:, :] == 0) and np.all(At[:, m:] == 0)            # zero padding stays zero
+    sc = ctx.debug_fetch(l, 5)
+    assert np.isclose(sc[0], z["pair_ll"], rtol=1e-13) and np.isclose(sc[1], z["pair_logdet"], rtol=1e-13)
+    gXu = ctx.debug_fetch(l, 4)[:m, :2]
+    assert _close(gXu, z["pair_gX"], 1e-11)
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(ll, z["ll"], rtol=1e-13) and _close(gX, z["gX"], 1e-11) and np.allclose(gC, z["gC"], rtol=1e-10)
+    g.close()
+
+
+def test_degenerate_blocks():
+    """empty block, 1-point block, exact tile multiples (16, 32), pairs with an empty side."""
+    z = load_golden("degenerate.npz")
+    g = _gprf_from_golden(z)
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(ll, z["ll"], rtol=1e-12)
+    assert _close(gX, z["gX"], 1e-10) and np.allclose(gC, z["gC"], rtol=1e-9)
+    g.close()
+
+
+def test_jitter_path_matches_jitchol():
+    """Duplicated points, zero noise: Cholesky hits an exactly zero pivot -> GPRF_NOT_PD -> the wrapper
+    applies jitchol's schedule (gpy_linalg.py:81-97): K + 1e-6*mean(diag) I succeeds.  cond ~ 1e6, so the
+    comparison is to rtol 1e-6."""
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov, _capi
+    z = load_golden("degenerate.npz")
+    X, Y, th = z["dup_X"], z["dup_Y"], z["dup_theta"]
+    g = GPRF(X, Y, None, GPCov([th[1]], th[2:], "euclidean", "se"), th[0], block_idxs=[np.arange(24)], neighbors=[])
+    rc, _, _, _, bad = g._ctx.eval(X, True, True)
+    assert rc == _capi.GPRF_NOT_PD and bad == 0
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(ll, z["dup_ll"], rtol=1e-6)
+    assert _close(gX, z["dup_gX"], 1e-5)
+    assert g._jitter[0] == pytest.approx(1e-6)
+    g.close()
+
+
+def test_not_pd_even_with_jitter_raises():
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov
+    X = np.zeros((20, 2))
+    Y = np.ones((20, 2))
+    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), -2.0, block_idxs=[np.arange(20)], neighbors=[])
+    with pytest.raises(np.linalg.LinAlgError):
+        g.llgrad(grad_X=True)
+    g.close()
+
+
+def test_unit_too_large_is_refused():
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov, _capi
+    X = np.random.RandomState(0).rand(600, 2)
+    Y = np.zeros((600, 2))
+    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), 0.01, block_idxs=[np.arange(600)], neighbors=[])
+    with pytest.raises(_capi.GprfHipError, match="at most 512"):
+        g.llgrad()
+    g.close()
+
+
+def test_max_size_unit_512():
+    """Largest supported unit: a 256+256 pair (mp = 512, 32 tiles)."""
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(4)
+    X = rng.rand(512, 2)
+    Y = rng.randn(512, 6)
+    blocks = [np.arange(0, 256), np.arange(256, 512)]
+    g = GPRF(X, Y, None, GPCov([1.0], [0.1, 0.1], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
+    r = GPRFRef(X, Y, None, OC([1.0], [0.1, 0.1], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
+    a = g.llgrad(grad_X=True, grad_cov=True)
+    b = r.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(a[0], b[0], rtol=1e-12) and _close(a[1], b[1], 1e-10) and np.allclose(a[2], b[2], rtol=1e-9)
+    g.close()
+
+
+def test_lld_matern32_toy():
+    """("lld","matern32") — parity-unpinned kernel (no treegp, no dataset): oracle restatement only."""
+    z = load_golden("lld_toy.npz")
+    g = _gprf_from_golden(z, dfn="lld", wfn="matern32")
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert gC.shape == (1, 4)                       # ncov = 2 + len(dfn_params) (gprf.py:578)
+    assert np.isclose(ll, z["ll"], rtol=1e-12)
+    assert _close(gX, z["gX"], 1e-9) and np.allclose(gC, z["gC"], rtol=1e-8)
+    g.close()
+
+
+def test_update_X_reblocks_and_update_covs():
+    """update_X re-runs block_fn (gprf.py:169-174); update_covs swaps hypers (gprf.py:160-167)."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(8)
+    X = rng.rand(400, 2)
+    Y = rng.randn(400, 5)
+    b = Blocker(grid_centers(9))
+    g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01, neighbors=b.neighbors())
+    r = GPRFRef(X, Y, b.block_clusters, OC([1.0], [0.2, 0.2], "euclidean", "se"), 0.01, neighbors=b.neighbors())
+    X2 = X + 0.05 * rng.randn(400, 2)              # points cross block borders
+    g.update_X(X2)
+    r.update_X(X2)
+    assert any(len(u) != len(v) for u, v in zip(b.block_clusters(X), g.block_idxs))
+    a, c = g.llgrad(grad_X=True), r.llgrad(grad_X=True)
+    assert np.isclose(a[0], c[0], rtol=1e-12) and _close(a[1], c[1], 1e-10)
+    FC = np.array([[0.02, 1.5, 0.25, 0.18]])
+    g.update_covs(FC)
+    r.update_covs(FC)
+    a, c = g.llgrad(grad_X=True, grad_cov=True), r.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(a[0], c[0], rtol=1e-12) and _close(a[1], c[1], 1e-10) and np.allclose(a[2], c[2], rtol=1e-9)
+    assert g.noise_var == 0.02 and list(g.cov.dfn_params) == [0.25, 0.18]
+    g.close()
+
+
+def test_two_shards_on_one_gpu_sum_to_full():
+    """The multi-GPU decomposition, exercised on one device: shard (0,2) + shard (1,2) partials add up to
+    the unsharded result; device-resident evaluation path (gprf_eval_device)."""
+    import torch
+    from gprf_amd import dist as gdist
+    z = load_golden("c1_small.npz")
+    full = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY")
+    ref = full.llgrad(grad_X=True, grad_cov=True)
+    parts = []
+    for rank in range(2):
+        g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY", shard=(rank, 2))
+        ev = gdist.DeviceEvaluator(g)
+        g._push_neighbors(g.neighbors)
+        ev.set_X(g.X)
+        ev.enqueue(True, True)
+        parts.append(ev.result(True, True))
+        assert 0 < g._ctx.num_units()[1] < 10
+        g.close()
+    assert np.isclose(parts[0][0] + parts[1][0], ref[0], rtol=1e-13)
+    assert _close(parts[0][1] + parts[1][1], ref[1], 1e-12)
+    assert np.allclose(parts[0][2] + parts[1][2], ref[2], rtol=1e-11)
+    full.close()
+
+
+def test_permutation_invariance_and_determinism():
+    """Size-independent properties: re-ordering points inside blocks leaves ll unchanged (to rounding) and
+    permutes gradX; repeated evaluation is bit-identical (fixed-order reductions, no float atomics)."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(9)
+    X = rng.rand(300, 2)
+    Y = rng.randn(300, 4)
+    blocks = [np.arange(0, 140), np.arange(140, 300)]
+    cov = GPCov([1.0], [0.3, 0.3], "euclidean", "se")
+    g = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=[(1, 0)])
+    a = g.llgrad(grad_X=True)
+    b = g.llgrad(grad_X=True)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    blocks2 = [rng.permutation(blocks[0]), rng.permutation(blocks[1])]
+    g2 = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks2, neighbors=[(1, 0)])
+    c = g2.llgrad(grad_X=True)
+    assert np.isclose(a[0], c[0], rtol=1e-12) and _close(c[1], a[1], 1e-10)
+    g.close(); g2.close()

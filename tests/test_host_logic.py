@@ -1,0 +1,135 @@
+"""Host-side logic of the product (no GPU): blocking, neighbour graph, CSR packing, objective transforms,
+synthetic recipe — each against the oracle's literal restatement of the reference."""
+import numpy as np
+import pytest
+
+from gprf_amd import Blocker, grid_centers, pair_distances
+from gprf_amd.gprf import _csr_from_block_idxs
+from gprf_amd import objective as pobj
+from gprf_amd import hostkernels
+from gprf_amd.cov import GPCov
+from oracle import harness_ref as H
+from oracle.vector_tree import VectorTree
+
+
+def test_grid_centers_round_up():
+    assert len(grid_centers(100)) == 100
+    assert len(grid_centers(800)) == 841
+    assert len(grid_centers(4)) == 4
+    c = np.array(grid_centers(4))
+    assert np.allclose(sorted(set(c[:, 0])), [0.25, 0.75])
+    assert np.allclose(np.array(grid_centers(9)), np.array(H.grid_centers(9)))
+
+
+@pytest.mark.parametrize("nb,expected", [(4, 6), (9, 20), (100, 342), (841, 3192)])
+def test_neighbors_are_the_8_neighbourhood(nb, expected):
+    nbrs = Blocker(grid_centers(nb)).neighbors()
+    assert len(nbrs) == expected                  # 342 pairs at 100 blocks, 3192 at 841
+    assert all(j < i for (i, j) in nbrs)
+    assert nbrs == H.BlockerRef(H.grid_centers(nb)).neighbors()
+    g = int(round(np.sqrt(nb)))
+    assert len(Blocker(grid_centers(nb)).neighbors(diag_connections=False)) == 2 * g * (g - 1)
+
+
+def test_block_clusters_match_reference_semantics():
+    rng = np.random.RandomState(5)
+    X = rng.rand(3000, 2) * 1.2 - 0.1             # some points outside the unit square
+    for nb in (4, 9, 100):
+        a = Blocker(grid_centers(nb)).block_clusters(X)
+        b = H.BlockerRef(H.grid_centers(nb)).block_clusters(X)
+        assert len(a) == len(b) == nb
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)           # same members, same (ascending) order
+    with np.errstate(invalid="ignore"):   # the a^2-2ab+b^2 self-distance can be sqrt(-1e-17) = nan
+        assert np.array_equal(pair_distances(X[:5], X[:7]), H.pair_distances(X[:5], X[:7]), equal_nan=True)
+
+
+def test_csr_packing():
+    blocks = [np.array([4, 1]), np.array([], dtype=int), np.array([0, 2, 3])]
+    ptr, pts = _csr_from_block_idxs(blocks)
+    assert ptr.tolist() == [0, 2, 2, 5] and pts.tolist() == [4, 1, 0, 2, 3]
+    assert pts.dtype == np.int32 and ptr.dtype == np.int64
+    ptr, pts = _csr_from_block_idxs([np.array([], dtype=int)])
+    assert ptr.tolist() == [0, 0] and len(pts) == 0
+
+
+class _FakeGPRF(object):
+    """Stands in for the device object so the callback's algebra can be checked on CPU."""
+
+    def __init__(self, n, dx):
+        self.n, self.dx = n, dx
+        self.rng = np.random.RandomState(0)
+
+    def update_X(self, X):
+        self.X = X
+
+    def update_covs(self, FC):
+        self.FC = FC.copy()
+
+    def llgrad(self, local=True, grad_X=False, grad_cov=False, parallel=False):
+        ll = -float(np.sum(self.X ** 2)) if grad_X else -1.0
+        gX = -2 * self.X if grad_X else np.zeros((0, 0))
+        gC = np.arange(1, 5, dtype=float).reshape(1, 4) * (self.FC[0, 2] if grad_cov else 1) if grad_cov else np.zeros((0, 0))
+        return ll, gX, gC
+
+
+class _SD(object):
+    def __init__(self, X_obs, obs_std):
+        self.X_obs, self.obs_std, self.noise_var = X_obs, obs_std, 0.01
+
+    x_prior = H.SampledDataRef.x_prior
+
+
+@pytest.mark.parametrize("task", ["x", "xcov", "cov4"])
+def test_objective_transforms_match_reference_callback(task):
+    rng = np.random.RandomState(1)
+    X0 = rng.rand(20, 2)
+    sd = _SD(X0 + 0.01 * rng.randn(20, 2), 0.05)
+    C0 = {"x": None, "xcov": np.array([[0.3]]), "cov4": np.array([[0.01, 1.0, 0.05, 0.05]])}[task]
+    Xarg = None if task == "cov4" else X0
+    a = pobj.Objective(_FakeGPRF(20, 2), Xarg, C0, sd)
+    b = H.ObjectiveRef(_FakeGPRF(20, 2), Xarg, C0, sd)
+    if task == "cov4":
+        a.gprf.X = b.gprf.X = X0
+    x = a.full0 + 0.01 * rng.randn(len(a.full0))
+    fa, ga = a(x)
+    fb, gb = b(x)
+    assert fa == fb and np.array_equal(ga, gb)
+    assert np.array_equal(a.full0, b.full0)
+    assert a.trace[0][0] == 0 and a.step == 1
+    assert pobj.cov_prior(np.array([0.3]))[0] == H.cov_prior(np.array([0.3]))[0]
+
+
+def test_log_line_format(tmp_path):
+    rng = np.random.RandomState(1)
+    X0 = rng.rand(6, 2)
+    o = pobj.Objective(_FakeGPRF(6, 2), X0, None, _SD(X0, 0.05), log_dir=str(tmp_path))
+    o(o.full0)
+    o.close()
+    lines = open(tmp_path / "log.txt").read().strip().split("\n")
+    f = lines[0].split()
+    assert f[0] == "0" and len(f) == 3 and "." in f[2] and len(f[2].split(".")[1]) == 2   # "%d %.2f %.2f"
+    assert lines[-1].startswith("optimization finished after")
+
+
+def test_host_kernels_match_oracle_c():
+    rng = np.random.RandomState(3)
+    X = rng.rand(30, 2)
+    c = GPCov([1.4], [0.2, 0.3], "euclidean", "se")
+    assert np.allclose(hostkernels.kernel_matrix(X, X, c), VectorTree(None, 1, "euclidean", [0.2, 0.3], "se", [1.4]).kernel_matrix(X, X, False), rtol=1e-14)
+    X3 = np.stack([130 + rng.randn(20), -2 + rng.randn(20), np.abs(rng.randn(20)) * 30], axis=1)
+    c = GPCov([0.9], [40.0, 20.0], "lld", "matern32")
+    assert np.allclose(hostkernels.kernel_matrix(X3, X3, c), VectorTree(None, 1, "lld", [40.0, 20.0], "matern32", [0.9]).kernel_matrix(X3, X3, False), rtol=1e-12)
+
+
+def test_synthetic_recipe_matches_oracle_recipe():
+    from gprf_amd.synthetic import SampledData
+    a = SampledData(n=700, ntrain=500, lscale=0.4, obs_std=0.04, yd=10, seed=0)
+    b = H.SampledDataRef(n=700, ntrain=500, lscale=0.4, obs_std=0.04, yd=10, seed=0)
+    assert np.array_equal(a.X_obs, b.X_obs) and np.array_equal(a.SX, b.SX)
+    assert np.allclose(a.SY, b.SY, rtol=0, atol=1e-11)
+    a.set_centers(grid_centers(4))
+    b.set_centers(H.grid_centers(4))
+    assert a.neighbors == b.neighbors
+    assert all(np.array_equal(u, v) for u, v in zip(a.block_idxs, b.block_idxs))
+    assert a.x_prior(a.X_obs.flatten() + 0.01)[0] == b.x_prior(b.X_obs.flatten() + 0.01)[0]
