@@ -185,6 +185,9 @@ def main():
         evs.append(ev)
         sizes_all.append(gdist.unit_sizes(blocks, nbrs))
     torch.cuda.synchronize()
+    # every evaluation of the timed region goes on ONE stream, strictly one after the other, as an
+    # optimiser would issue them (no overlap between consecutive evaluations)
+    run_stream = torch.cuda.Stream(device=dev)
 
     def barrier():
         if world > 1:
@@ -193,14 +196,14 @@ def main():
 
     # ---------------- warmup, then EXACTLY --steps timed steps
     for k in range(args.warmup):
-        evs[k % nX].enqueue(True, grad_cov)
+        evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
     barrier()
     for ev in evs:
         ev.g._ctx.set_timing(True, reset=True)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        evs[k % nX].enqueue(True, grad_cov)
+        evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
     barrier()
     elapsed = time.perf_counter() - t0
     for ev in evs:
@@ -270,7 +273,7 @@ def main():
         ts = []
         for k in range(min(args.steps, 50)):
             t1 = time.perf_counter()
-            evs[k % nX].enqueue(True, grad_cov)
+            evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
             evs[k % nX].result(True, grad_cov)
             ts.append(time.perf_counter() - t1)
         result["sync_evals_per_s"] = 1.0 / float(np.median(ts))
@@ -289,11 +292,11 @@ def main():
         gl._push_neighbors(gl.neighbors)
         el.set_X(sd.X_obs)
         for _ in range(10):
-            el.enqueue(True, grad_cov)
+            el.enqueue(True, grad_cov, stream=run_stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(100):
-            el.enqueue(True, grad_cov)
+            el.enqueue(True, grad_cov, stream=run_stream)
         torch.cuda.synchronize()
         result["local_gp_evals_per_s"] = 100.0 / (time.perf_counter() - t1)
         gl.close()

@@ -76,20 +76,26 @@ class DeviceEvaluator(object):
         ctx = gprf._ctx
         self.n, self.dx, self.ncov = ctx.n, ctx.dx, ctx.ncov
         dev = torch.device("cuda", torch.cuda.current_device())
+        # a real (non-null) stream: the kernels, the RCCL all-reduce and torch's events all sit on it
+        self.stream = torch.cuda.Stream(device=dev)
         self.d_X = torch.empty(self.n * self.dx, dtype=torch.float64, device=dev)
         self.d_out = torch.empty(1 + self.n * self.dx + self.ncov, dtype=torch.float64, device=dev)
 
     def set_X(self, X):
-        self.d_X.copy_(self.torch.as_tensor(np.ascontiguousarray(X, dtype=np.float64).reshape(-1)))
+        with self.torch.cuda.stream(self.stream):
+            self.d_X.copy_(self.torch.as_tensor(np.ascontiguousarray(X, dtype=np.float64).reshape(-1)))
+        self.stream.synchronize()
 
-    def enqueue(self, grad_X=True, grad_cov=False):
-        """Enqueue one evaluation (+ the all-reduce) on the current stream; returns immediately."""
-        stream = self.torch.cuda.current_stream().cuda_stream
-        self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), stream)
-        allreduce_sum_(self.d_out, self.group)
+    def enqueue(self, grad_X=True, grad_cov=False, stream=None):
+        """Enqueue one evaluation (+ the all-reduce) on ``stream`` (default: this evaluator's own);
+        returns immediately."""
+        st = self.stream if stream is None else stream
+        with self.torch.cuda.stream(st):
+            self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream)
+            allreduce_sum_(self.d_out, self.group)
 
     def result(self, grad_X=True, grad_cov=False):
-        self.torch.cuda.current_stream().synchronize()
+        self.torch.cuda.synchronize()
         rc, bad = self.g._ctx.eval_status()
         if rc == _capi.GPRF_NOT_PD:
             raise _capi.NotPositiveDefinite("unit %d: kernel matrix not positive definite" % bad, bad)
