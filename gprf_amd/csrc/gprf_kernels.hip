@@ -22,6 +22,8 @@
 //                        ll      = -1/2 ||Z||_F^2 - dy sum log U_kk - 1/2 dy m log 2pi (gprf.py:542-544).
 #include "gprf_kernels.h"
 
+#include <cstdlib>
+
 namespace gprf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -342,6 +344,210 @@ __global__ __launch_bounds__(POTRF_WAVES * 64) void k_potrf(UnitTab ut, Pools pl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_potrf2: the same blocked upper Cholesky, re-scheduled around its critical path
+//     diag(j) -> row panel(j) -> update of tile (j+1,j+1) -> diag(j+1) -> ...
+// * look-ahead: once row panel j is in LDS, wave 0 alone updates tile (j+1,j+1) and factors it while
+//   waves 1..7 apply the rest of the trailing update (MFMA, both operands from the LDS panel);
+// * the 16x16 diagonal factor keeps one column per lane and broadcasts with v_readlane; it scales by the
+//   reciprocal of the pivot's root, as LAPACK's dpotf2 does;
+// * the row panel U_jk = U_jj^-T C_jk is a true forward substitution on the vector ALU (one matrix column
+//   per lane, U_jj broadcast from LDS) — no explicit inverse on the critical path, and backward stable;
+// * V_jj = U_jj^-1 (wanted by the triangular-solve kernel's MFMA form) is built after the loop, four tiles
+//   per wave at once, by the column operations that reduce U_jj to I;
+// * log|K| = 2 sum log U_kk (gpy_linalg.py:234) from the stored diagonal, in parallel, fixed order.
+// ------------------------------------------------------------------------------------------------
+// upper Cholesky of one 16x16 tile held one column per lane (s[i] = C[i][lr]); returns the first bad pivot
+// (1-based row within the tile) or 0; *dk / *rdk = this lane's diagonal entry and its reciprocal
+__device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk, double *rdk) {
+    int bad = 0;
+    double mydiag = 1.0, myrd = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double pkk = readlane_d(s[k], k);
+        bool isbad = !(pkk > 0.0);
+        bad = (isbad && bad == 0) ? (k + 1) : bad;
+        pkk = isbad ? 1.0 : pkk;
+        double d = sqrt(pkk);
+        double rd = 1.0 / d;
+        double ukc = (lr > k) ? s[k] * rd : ((lr == k) ? d : 0.0);
+        s[k] = ukc;
+#pragma unroll
+        for (int i = k + 1; i < 16; ++i) s[i] -= readlane_d(ukc, i) * ukc;
+        mydiag = (lr == k) ? d : mydiag;
+        myrd = (lr == k) ? rd : myrd;
+    }
+    *dk = mydiag;
+    *rdk = myrd;
+    return bad;
+}
+
+__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pools pl) {
+    extern __shared__ double lds[];
+    __shared__ int s_fail;
+    __shared__ double lred[POTRF_WAVES];
+    int u = blockIdx.x;
+    int m = ut.m[u];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    if (m == 0) {
+        if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
+        return;
+    }
+    int mp = pad16(m), T = mp >> 4;
+    int ldp = mp + ((T & 1) ? 0 : 16);
+    double *P = lds;                      // [16][ldp] row panel j of U
+    double *Ud = P + 16 * ldp;            // [16][16]  U_jj
+    double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
+    double *Tt = rdt + 16;                // [16][17]  look-ahead tile, row-major
+    double *dvals = Tt + 16 * 17;         // [mp]      diagonal of U
+    double *U = pl.U + ut.mat_off[u];
+    double *V = pl.V + (size_t)ut.row_off[u] * 16;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+
+    // publish a factored diagonal tile (wave 0): global U, LDS Ud / rdt / dvals
+    auto publish = [&](double (&s)[16], double dk, double rdk, int jt, int bad) {
+        if (lane < 16) {
+            double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double uv = (i <= lr) ? s[i] : 0.0;
+                Ujj[(size_t)i * mp + lr] = uv;
+                Ud[i * 16 + lr] = uv;
+            }
+            rdt[lr] = rdk;
+            dvals[16 * jt + lr] = dk;
+            if (bad && lane == 0) s_fail = 16 * jt + bad;
+        }
+    };
+    if (wave == 0) {
+        double s[16], dk, rdk;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = U[(size_t)i * mp + lr];
+        int bad = diag_factor16(s, lr, &dk, &rdk);
+        publish(s, dk, rdk, 0, bad);
+    }
+    __syncthreads();
+
+    for (int j = 0; j < T; ++j) {
+        if (s_fail) {
+            if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
+            return;
+        }
+        int ntr = T - j - 1;
+        if (ntr == 0) break;
+        // ---- row panel by forward substitution: 64 columns per wave task, one column per lane ----
+        int ncol = 16 * ntr;
+        for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
+            int col = 16 * (j + 1) + c0 + lane;
+            if (c0 + lane < ncol) {
+                double x[16];
+                double *Cc = U + (size_t)(16 * j) * mp + col;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) x[a] = Cc[(size_t)a * mp];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    x[c] *= rdt[c];
+#pragma unroll
+                    for (int a = c + 1; a < 16; ++a) x[a] -= Ud[c * 16 + a] * x[c];
+                }
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    Cc[(size_t)a * mp] = x[a];
+                    P[a * ldp + col] = x[a];
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // look-ahead: tile (j+1, j+1) -> LDS (row-major) -> one column per lane -> factor
+            int i = j + 1;
+            const double *Cii = U + (size_t)(16 * i + lg) * mp + 16 * i + lr;
+            d4 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = Cii[(size_t)(4 * q) * mp];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double a = P[(4 * s + lg) * ldp + 16 * i + lr];
+                acc = mfma(-a, a, acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Tt[(lg + 4 * q) * 17 + lr] = acc[q];
+            __builtin_amdgcn_wave_barrier();    // same wave, LDS is in order: the reads below see the tile
+            double s[16], dk, rdk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = Tt[r * 17 + lr];
+            int bad = diag_factor16(s, lr, &dk, &rdk);
+            publish(s, dk, rdk, i, bad);
+        } else {
+            // trailing update without tile (j+1,j+1): tiles (i,k), j < i <= k < T, linear index t >= 1
+            int ntile = ntr * (ntr + 1) / 2;
+            for (int t = wave; t < ntile; t += POTRF_WAVES - 1) {
+                int a_ = 0, rem = t;
+                while (rem >= ntr - a_) { rem -= ntr - a_; ++a_; }
+                int i = j + 1 + a_, k = i + rem;
+                double *Cik = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
+                d4 acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = Cik[(size_t)(4 * q) * mp];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
+                    double b = P[(4 * s + lg) * ldp + 16 * k + lr];
+                    acc = mfma(a, b, acc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = acc[q];
+            }
+        }
+        __syncthreads();
+    }
+    if (s_fail) {
+        if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
+        return;
+    }
+    // ---- V_jj = U_jj^-1 for every diagonal tile: 4 tiles per wave at a time, lane (lg, lr) = row lr of
+    //      tile 4*grp + lg;  apply to I the column operations that reduce U_jj to I ----
+    for (int grp = wave; 4 * grp < T; grp += POTRF_WAVES) {
+        int jt = 4 * grp + lg;
+        double *Us = P + jt * 256;            // the panel buffer is free now: 256 T <= 16 ldp doubles
+        if (jt < T) {
+            const double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Us[i * 16 + lr] = Ujj[(size_t)i * mp + lr];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (jt < T) {
+            double v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = (c == lr) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] *= 1.0 / Us[k * 16 + k];
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) v[i] -= Us[k * 16 + i] * v[k];
+            }
+            double *Vj = V + (size_t)jt * 256 + lr * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Vj[c] = v[c];
+        }
+    }
+    // ---- log-determinant ----
+    double part = 0.0;
+    for (int r = threadIdx.x; r < mp; r += POTRF_WAVES * 64) part += log(dvals[r]);
+    for (int off = 32; off >= 1; off >>= 1) part += shfl_xor_d(part, off);
+    if (lane == 0) lred[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < POTRF_WAVES; ++w) t += lred[w];
+        pl.logdet[u] = 2.0 * t;
+        pl.info[u] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward substitution  U^T [W | Z] = [I | Yu]  (replaces dtrtri/dpotri/dpotrs of gpy_linalg.py:219-253,
 // 139-148): one workgroup per 16-column block of the right-hand side, right-looking, the block's
@@ -445,6 +651,126 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
             pl.zzpart[(size_t)u * 4 + cb] = t;
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Forward substitution, register-resident form (units with T <= SOLVE2_MAXT): ONE WAVE per 16-column block
+// of [I | Yu].  The block's tiles for all rows stay in MFMA accumulators; the freshly solved tile w_r is
+// already in B-operand layout (accumulator register q = rows 4q+lg), so the right-looking updates
+// acc_r' -= U_{r,r'}^T w_r chain through registers with no LDS and no barrier.  Only U tiles (shared by
+// the 4 waves of the workgroup through L1) and the 16x16 diagonal inverses are read from memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int SOLVE2_MAXT = 18;  // largest instantiation: 18 tiles x 8 VGPRs of accumulators, 2 waves/SIMD
+
+template <int SOLVE2_MAXT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    int cbx = blockIdx.x * 4 + wave;
+    bool is_y = cbx >= ut.max_T;
+    int cb = is_y ? (cbx - ut.max_T) : cbx;
+    if (is_y ? (cb >= 4) : (cb >= T)) return;
+    size_t roff = ut.row_off[u];
+    if (T == 0) {
+        if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
+        return;
+    }
+    const double *__restrict__ U = pl.U + ut.mat_off[u];
+    const double *__restrict__ V = pl.V + roff * 16;
+    double *__restrict__ W = pl.W + ut.mat_off[u];
+    double *__restrict__ Z = pl.Z + roff * YPAD;
+    const double *__restrict__ Yu = pl.Yu + roff * YPAD;
+    int r0 = is_y ? 0 : cb;
+
+    d4 acc[SOLVE2_MAXT];
+#pragma unroll
+    for (int t = 0; t < SOLVE2_MAXT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = 0.0;
+            if (r0 + t < T) {
+                if (is_y) v = Yu[(size_t)(16 * (r0 + t) + lg + 4 * q) * YPAD + 16 * cb + lr];
+                else v = (t == 0 && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+            }
+            acc[t][q] = v;
+        }
+    }
+    double zz = 0.0;
+#pragma unroll
+    for (int t = 0; t < SOLVE2_MAXT; ++t) {
+        int r = r0 + t;
+        if (r < T) {
+            const double *Vr = V + (size_t)r * 256 + lg * 16 + lr;
+            d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w = mfma(Vr[64 * s], acc[t][s], w);
+            if (is_y) {
+                double *zp = Z + (size_t)(16 * r + lg) * YPAD + 16 * cb + lr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zp[(size_t)(4 * q) * YPAD] = w[q];
+                    zz += w[q] * w[q];
+                }
+            } else {
+                double *wp = W + (size_t)(16 * r + lg) * mp + 16 * cb + lr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wp[(size_t)(4 * q) * mp] = w[q];
+            }
+            // rows below: acc_{r'} -= U_{r,r'}^T w   (tile (r, r') of U, r' = r0 + t2 > r)
+            const double *Ur = U + (size_t)(16 * r + lg) * mp + 16 * r0 + lr;
+            const double *u0 = Ur, *u1 = Ur + (size_t)4 * mp, *u2 = Ur + (size_t)8 * mp, *u3 = Ur + (size_t)12 * mp;
+#pragma unroll
+            for (int t2 = t + 1; t2 < SOLVE2_MAXT; ++t2) {
+                if (r0 + t2 < T) {
+                    acc[t2] = mfma(-u0[16 * t2], w[0], acc[t2]);
+                    acc[t2] = mfma(-u1[16 * t2], w[1], acc[t2]);
+                    acc[t2] = mfma(-u2[16 * t2], w[2], acc[t2]);
+                    acc[t2] = mfma(-u3[16 * t2], w[3], acc[t2]);
+                }
+            }
+        }
+    }
+    if (is_y) {
+        for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
+        if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = zz;
+    }
+}
+
+// At = Z^T W, one wave per column tile I of the unit computing all four 16-row blocks of At (the W tile is
+// the shared B operand: 5 loads per 4 MFMAs).
+__global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
+    int u = blockIdx.y;
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int I = blockIdx.x * 4 + wave;
+    if (I >= T) return;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    const double *__restrict__ Z = pl.Z + roff * YPAD;
+    double *__restrict__ At = pl.At + roff * YPAD;
+    d4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int kt = I; kt < T; ++kt) {
+        const double *wp = W + (size_t)(16 * kt + lg) * mp + 16 * I + lr;
+        const double *zp = Z + (size_t)(16 * kt + lg) * YPAD + lr;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double b = wp[(size_t)(4 * s) * mp];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma(zp[(size_t)(4 * s) * YPAD + 16 * c], b, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[c][q];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -648,6 +974,12 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// A/B switches for kernel generations (bring-up and interleaved timing only): env var set and != "0".
+static bool variant_flag(const char *name) {
+    const char *v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
     if (total_rows == 0) return;
     hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);
@@ -678,16 +1010,36 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
+    if (!variant_flag("GPRF_POTRF_V1")) {
+        size_t lds2 = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
+        static size_t lds2_set = 0;
+        if (lds2 > 48 * 1024 && lds2 > lds2_set) {
+            (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            lds2_set = lds2;
+        }
+        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_units), dim3(POTRF_WAVES * 64), lds2, s, ut, p);
+        return;
+    }
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_units), dim3(POTRF_WAVES * 64), lds, s, ut, p);
 }
 
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_units == 0) return;
+    if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
+        dim3 grid((ut.max_T + 4 + 3) / 4, ut.n_units);
+        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
+        else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
+        return;
+    }
     hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_units), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
 }
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_units == 0 || ut.max_T == 0) return;
+    if (!variant_flag("GPRF_AT_V1")) {
+        hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_units), dim3(256), 0, s, ut, p);
+        return;
+    }
     hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_units), dim3(256), 0, s, ut, p);
 }
 

@@ -72,13 +72,13 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20):
     nbrs = b.neighbors() if pairs else []
     g = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=nbrs)
     t = time.time(); r = g.llgrad(grad_X=True); t1 = time.time() - t
-    g._ctx.set_timing(True)
+    g._ctx.set_timing(True, reset=True)
     ts = []
     for _ in range(reps):
         t = time.time(); r = g.llgrad(grad_X=True); ts.append(time.time() - t)
     st = g._ctx.get_timing()
     print(" timing n=%d nb=%d pairs=%d: first %.1f ms, median %.3f ms; stages(ms) %s; work %s" % (
-        n, nb, len(nbrs), t1 * 1e3, np.median(ts) * 1e3, {k: round(v, 3) for k, v in st.items()}, g._ctx.work_estimate()))
+        n, nb, len(nbrs), t1 * 1e3, np.median(ts) * 1e3, {k: round(v, 4) for k, v in st.items()}, g._ctx.work_estimate()))
     g.close()
 
 
