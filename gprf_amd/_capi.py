@@ -76,6 +76,7 @@ def load(build_if_missing=True):
         _build.build()
     if not os.path.exists(path):
         raise GprfHipError("libgprf_hip.so is missing (%s); run `python -m gprf_amd.build`" % path)
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -83,6 +84,26 @@ def load(build_if_missing=True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.  If this library
+    pulled in /opt/rocm's copy first, a later ``import torch`` in the same process would find a second,
+    mismatched runtime already bound to the SONAME and fail to see the GPU.  So when a torch wheel with a
+    bundled runtime is installed, load that copy first (RTLD_GLOBAL); libgprf_hip.so then binds to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def partition_units(m, dy, world):

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -85,12 +86,23 @@ struct gprf_ctx {
 
     // device state
     DevBuf<double> d_X, d_Y, d_out;
-    DevBuf<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_info;
+    DevBuf<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_info, d_row_unit;
     DevBuf<int64_t> d_matoff, d_slot_ptr;
     DevBuf<double> d_weight, d_jitter, d_slot_w;
-    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart;
+    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
+
+    // stream groups: the local units are dealt round-robin (by descending cost) into n_groups sets; each set's
+    // fill->potrf->solve->at->grad chain runs on its own stream so that the latency-bound factorisation
+    // of one set overlaps the throughput-bound stages of another; joined before the assembly
+    static constexpr int MAX_GROUPS = 8;
+    int n_groups = 1;
+    hipStream_t gstream[MAX_GROUPS] = {};
+    hipEvent_t gev_start = nullptr, gev_done[MAX_GROUPS] = {};
+    bool groups_ready = false;
+    int group_begin[MAX_GROUPS + 1] = {};   // ranges into d_ids
+    DevBuf<int32_t> d_ids;
 
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
@@ -130,8 +142,11 @@ UnitTab make_tab(gprf_ctx *c) {
     t.weight = c->d_weight.p;
     t.jitter = c->d_jitter.p;
     t.upt = c->d_upt.p;
+    t.row_unit = c->d_row_unit.p;
     t.n_units = c->n_local;
     t.max_T = c->max_T;
+    t.ids = c->d_ids.p;
+    t.n_ids = c->n_local;
     return t;
 }
 
@@ -139,7 +154,7 @@ Pools make_pools(gprf_ctx *c) {
     Pools p;
     p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
-    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p;
+    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p;
     return p;
 }
 
@@ -211,6 +226,11 @@ int rebuild_units(gprf_ctx *c) {
 
     // unit row -> point table and the point -> slots CSR for the deterministic gather (gprf.py:258-273)
     std::vector<int32_t> upt((size_t)rows, -1);
+    std::vector<int32_t> row_unit((size_t)rows, 0);
+    for (int l = 0; l < nl; ++l) {
+        int mp = pad16(c->l_m[l]);
+        std::fill(row_unit.begin() + c->l_rowoff[l], row_unit.begin() + c->l_rowoff[l] + mp, l);
+    }
     std::vector<int64_t> slot_cnt((size_t)c->n + 1, 0);
     for (int l = 0; l < nl; ++l) {
         int u = c->l_global[l];
@@ -245,9 +265,26 @@ int rebuild_units(gprf_ctx *c) {
         }
     }
 
+    // unit id lists: group g = every n_groups-th unit in descending-cost order (group 0 when n_groups == 1
+    // is simply all units, largest first, so that the long factorizations start first)
+    std::vector<int32_t> ids(nl);
+    {
+        std::vector<int> order(nl);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->l_m[a] > c->l_m[b]; });
+        int G = std::max(1, std::min(c->n_groups, gprf_ctx::MAX_GROUPS));
+        int pos = 0;
+        for (int g = 0; g < G; ++g) {
+            c->group_begin[g] = pos;
+            for (int k = g; k < nl; k += G) ids[pos++] = order[k];
+        }
+        for (int g = G; g <= gprf_ctx::MAX_GROUPS; ++g) c->group_begin[g] = pos;
+    }
+
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     size_t nl1 = (size_t)std::max(nl, 1);
+    HIP_TRY(c, c->d_ids.reserve(nl1));
     HIP_TRY(c, c->d_m.reserve(nl1));
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_matoff.reserve(nl1));
@@ -259,6 +296,8 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->h_info.reserve(nl1));
     HIP_TRY(c, c->d_gcpart.reserve(nl1 * (size_t)std::max(maxT, 1) * GC_SLOTS));
     HIP_TRY(c, c->d_upt.reserve((size_t)rows + 1));
+    HIP_TRY(c, c->d_row_unit.reserve((size_t)rows + 1));
+    HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * MAX_TB * XPAD + 1));
     HIP_TRY(c, c->d_slot_ptr.reserve((size_t)c->n + 1));
     HIP_TRY(c, c->d_slot_row.reserve(slot_row.size() + 1));
     HIP_TRY(c, c->d_slot_w.reserve(slot_w.size() + 1));
@@ -275,13 +314,16 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, hipStreamSynchronize(s));
     if (nl > 0) {
         HIP_TRY(c, hipMemcpy(c->d_m.p, c->l_m.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_ids.p, ids.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_rowoff.p, c->l_rowoff.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_matoff.p, c->l_matoff.data(), nl * sizeof(int64_t), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_weight.p, weight.data(), nl * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_jitter.p, jitter.data(), nl * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (rows > 0)
+    if (rows > 0) {
         HIP_TRY(c, hipMemcpy(c->d_upt.p, upt.data(), (size_t)rows * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_row_unit.p, row_unit.data(), (size_t)rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemcpy(c->d_slot_ptr.p, slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     if (!slot_row.empty()) {
         HIP_TRY(c, hipMemcpy(c->d_slot_row.p, slot_row.data(), slot_row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -347,21 +389,55 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     }
     int stage = 0;
     auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[slot][stage], s); ++stage; };
-    mark();
-    launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
-    mark();
-    launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
-    mark();
-    if (stop_after >= 1) launch_potrf(ut, pl, s);
-    mark();
-    if (stop_after >= 2) launch_solve(ut, pl, s);
-    mark();
-    if (stop_after >= 3) launch_at(ut, pl, s);
-    mark();
-    if (stop_after >= 4 && (want_gx || want_gc)) launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, s);
-    mark();
-    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
-    mark();
+    int G = std::max(1, std::min(c->n_groups, gprf_ctx::MAX_GROUPS));
+    bool do_grad = stop_after >= 4 && (want_gx || want_gc);
+    if (G == 1 || tm) {
+        mark();
+        launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
+        mark();
+        launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
+        mark();
+        if (stop_after >= 1) launch_potrf(ut, pl, s);
+        mark();
+        if (stop_after >= 2) launch_solve(ut, pl, s);
+        mark();
+        if (stop_after >= 3) launch_at(ut, pl, s);
+        mark();
+        if (do_grad) {
+            launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, (int)c->total_rows, s);
+            launch_gx_finalize(ut, pl, (int)c->total_rows, s);
+        }
+        mark();
+        if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+        mark();
+    } else {
+        if (!c->groups_ready) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->gev_start, hipEventDisableTiming));
+            for (int g = 0; g < gprf_ctx::MAX_GROUPS; ++g) {
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->gev_done[g], hipEventDisableTiming));
+            }
+            c->groups_ready = true;
+        }
+        launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
+        HIP_TRY(c, hipEventRecord(c->gev_start, s));
+        for (int g = 0; g < G; ++g) {
+            UnitTab ug = ut;
+            ug.ids = c->d_ids.p + c->group_begin[g];
+            ug.n_ids = c->group_begin[g + 1] - c->group_begin[g];
+            hipStream_t gs = c->gstream[g];
+            HIP_TRY(c, hipStreamWaitEvent(gs, c->gev_start, 0));
+            launch_fill(c->dist_id, c->kern_id, ug, pl, kp, gs);
+            if (stop_after >= 1) launch_potrf(ug, pl, gs);
+            if (stop_after >= 2) launch_solve(ug, pl, gs);
+            if (stop_after >= 3) launch_at(ug, pl, gs);
+            if (do_grad) launch_grad(c->dist_id, c->kern_id, ug, pl, kp, want_gc, (int)c->total_rows, gs);
+            HIP_TRY(c, hipEventRecord(c->gev_done[g], gs));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->gev_done[g], 0));
+        }
+        if (do_grad) launch_gx_finalize(ut, pl, (int)c->total_rows, s);
+        if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+    }
     HIP_TRY(c, hipGetLastError());
     // unit status -> pinned host
     if (c->n_local > 0)
@@ -406,6 +482,7 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     c->n = n; c->dx = dx; c->dy = dy; c->dist_id = dist_id; c->kern_id = kern_id; c->device = device;
     c->ndfn = se ? dx : 2;
     c->ncov = 2 + c->ndfn;
+    if (const char *g = getenv("GPRF_GROUPS")) c->n_groups = std::max(1, std::min(atoi(g), (int)gprf_ctx::MAX_GROUPS));
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return GPRF_ERR_HIP;
@@ -430,10 +507,19 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
     c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
-    c->d_gcpart.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
+    c->d_gcpart.release(); c->d_rowpart.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
+    if (c->groups_ready) {
+        (void)hipEventDestroy(c->gev_start);
+        for (int g = 0; g < gprf_ctx::MAX_GROUPS; ++g) {
+            (void)hipStreamSynchronize(c->gstream[g]);
+            (void)hipStreamDestroy(c->gstream[g]);
+            (void)hipEventDestroy(c->gev_done[g]);
+        }
+    }
+    c->d_ids.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;

@@ -12,6 +12,7 @@ constexpr int MAX_T = MAX_MP / TILE;
 constexpr int YPAD = 64;          // dy padded to 4 column tiles
 constexpr int XPAD = 4;           // dx padded (dx <= 3)
 constexpr int GC_SLOTS = 8;       // per-(unit, column-tile) hyper-gradient partials
+constexpr int MAX_TB = MAX_T / 4;   // 64-point blocks per unit edge (k_grad2's row-sum slab)
 
 // Kernel hyper-parameters, passed by value.  theta = [nv, sv, ls...] (gprf.py:160-164).
 struct KParams {
@@ -28,6 +29,9 @@ struct UnitTab {
     const double *weight;    // Bethe weight: 1 - deg(i) for unaries, 1 for pairs
     const double *jitter;    // extra diagonal (jitchol retry)
     const int32_t *upt;      // [total padded rows] global point index of each unit row, -1 for padding
+    const int32_t *row_unit; // [total padded rows] local unit id of each padded row
+    const int32_t *ids;      // the local unit ids this launch covers (one stream group) ...
+    int n_ids;               // ... and how many
     int n_units;
     int max_T;               // max over units of mp/16
 };
@@ -41,6 +45,7 @@ struct Pools {
     double *Z;     // U^-T Yu, YPAD per padded row
     double *At;    // (K^-1 Yu)^T : per unit YPAD x mp at YPAD*row_off
     double *gXu;   // per-unit-row gradient slab, XPAD per padded row
+    double *rowpart;  // k_grad2: per padded row, MAX_TB x XPAD partial row sums (one per column block)
     double *logdet;   // per unit
     double *zzpart;   // per unit x 4 : partial sums of ||Z||_F^2 per Y column block
     double *gcpart;   // per unit x max_T x GC_SLOTS
@@ -60,8 +65,10 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 hipStream_t s);
+                 int total_rows, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s);
+bool grad_uses_blocks();  // true when launch_grad runs k_grad2 (gcpart indexed by 64-point column block)
 
 }  // namespace gprf

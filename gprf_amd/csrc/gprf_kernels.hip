@@ -76,6 +76,20 @@ struct KernFn<0, 0> {
         }
         return k;
     }
+    // both ends' derivatives from a kernel value already in hand (have_k) or recomputed
+    __device__ static __forceinline__ double pair(const KParams &p, const double *xi, const double *xj, bool have_k,
+                                                  double kval, double *dkdxi, double *dkdxj, double *dkdl) {
+        double k = have_k ? kval : value(p, xi, xj);
+        for (int d = 0; d < p.dx; ++d) {
+            double delta = xj[d] - xi[d];
+            double l = p.ls[d];
+            double t = -2.0 * delta / (l * l) * k;
+            dkdxj[d] = t;
+            dkdxi[d] = -t;
+            dkdl[d] = 2.0 * delta * delta / (l * l * l) * k;
+        }
+        return k;
+    }
 };
 
 // great-circle pieces shared by the lld distance: a = haversine argument, g = km
@@ -137,6 +151,14 @@ struct KernFn<1, 1> {
         dkdl[1] = -c * dz * dz / (l1 * l1 * l1);
         return k;
     }
+    // the great-circle derivatives are not antisymmetric in the two ends: evaluate both
+    __device__ static __forceinline__ double pair(const KParams &p, const double *xi, const double *xj, bool, double,
+                                                  double *dkdxi, double *dkdxj, double *dkdl) {
+        double tmp[3];
+        double k = full(p, xi, xj, dkdxj, dkdl);
+        (void)full(p, xj, xi, dkdxi, tmp);
+        return k;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -171,7 +193,7 @@ __global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__rest
 // ------------------------------------------------------------------------------------------------
 template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int nt64) {
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m);
     int ti = blockIdx.x / nt64, tj = blockIdx.x % nt64;
@@ -221,7 +243,7 @@ constexpr int POTRF_WAVES = 8;
 __global__ __launch_bounds__(POTRF_WAVES * 64) void k_potrf(UnitTab ut, Pools pl) {
     extern __shared__ double lds[];
     __shared__ int s_fail;
-    int u = blockIdx.x;
+    int u = ut.ids[blockIdx.x];
     int m = ut.m[u];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int lr = lane & 15, lg = lane >> 4;
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
-    int u = blockIdx.x;
+    int u = ut.ids[blockIdx.x];
     int m = ut.m[u];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int lr = lane & 15, lg = lane >> 4;
@@ -561,7 +583,7 @@ constexpr int SOLVE_SLOTS = MAX_T / SOLVE_WAVES;  // 8
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl) {
     __shared__ double Wr[2][256];
     __shared__ double zred[SOLVE_WAVES];
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int bx = blockIdx.x;
@@ -665,7 +687,7 @@ constexpr int SOLVE2_MAXT = 18;  // largest instantiation: 18 tiles x 8 VGPRs of
 
 template <int SOLVE2_MAXT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -743,7 +765,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
 // At = Z^T W, one wave per column tile I of the unit computing all four 16-row blocks of At (the W tile is
 // the shared B operand: 5 loads per 4 MFMAs).
 __global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -778,7 +800,7 @@ __global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
 // with the explicit W).  Workgroup per column tile I of the unit, wave = 16-row block of At (Y columns).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_at(UnitTab ut, Pools pl) {
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int I = blockIdx.x;
@@ -814,7 +836,7 @@ template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_grad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double red[4][16][8];
     __shared__ double gcred[4][8];
-    int u = blockIdx.y;
+    int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int J = blockIdx.x;
@@ -912,13 +934,269 @@ __global__ __launch_bounds__(256) void k_grad(UnitTab ut, Pools pl, KParams kp, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_grad2: the same reduction on the LOWER triangle of M only, with LDS-staged operands.
+// Workgroup = (unit, 64-column block JB); it walks the 64-row blocks IB >= JB.  For a block pair the K-loop
+// runs over 16-row chunks of the stacked operand [At ; W] (both row-major with leading dimension mp):
+// a chunk's 64 I-columns and 64 J-columns are staged once in LDS (double buffered, one barrier per chunk)
+// and feed all 16 tile products of the block: wave w owns row tile I = 4 IB + w against the four J tiles
+// (1 A read + 4 B reads per 4 MFMAs).  M = At^T At - dy W^T W is symmetric and so is k, hence a strictly
+// lower tile (I > J) contributes its column sums to gradX of the J points AND its row sums to gradX of the I
+// points (and twice to the hyper-parameter sums); its k values are read back from the strictly-lower part of
+// the K/U pool, which the Cholesky never touches — only diagonal tiles re-evaluate exp().
+// Row sums leave through rowpart[row][JB] and are folded into gXu by k_gx_finalize (fixed order).
+// ------------------------------------------------------------------------------------------------
+constexpr int G2_LD = 144;   // staged chunk row stride in doubles: 128 columns + 16 (lane groups 32 banks apart)
+
+// sum over the 16 lanes of a DPP row (the lr index), result in every lane: rotate-and-add
+__device__ __forceinline__ double row16_sum(double v) {
+#define GPRF_ROR_ADD(n)                                                                                  \
+    {                                                                                                    \
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + (n), 0xf, 0xf, false);        \
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + (n), 0xf, 0xf, false);        \
+        v += __hiloint2double(hi, lo);                                                                   \
+    }
+    GPRF_ROR_ADD(8) GPRF_ROR_ADD(4) GPRF_ROR_ADD(2) GPRF_ROR_ADD(1)
+#undef GPRF_ROR_ADD
+    return v;
+}
+
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams kp, int want_gc, int ablate) {
+    __shared__ double chunk[2][16 * G2_LD];
+    __shared__ double red[4][64][4];
+    __shared__ double gcred[4][8];
+    int u = ut.ids[blockIdx.y];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int TB = (T + 3) >> 2;
+    int JB = blockIdx.x;
+    if (JB >= TB) return;
+    int tid = threadIdx.x;
+    int lane = tid & 63, wave = tid >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    const double *__restrict__ Kp = pl.U + ut.mat_off[u];     // strictly-lower tiles still hold K
+    const double *__restrict__ At = pl.At + roff * YPAD;
+    const double *__restrict__ Xu = pl.Xu + roff * XPAD;
+    int J0 = 4 * JB;
+    double dyd = (double)kp.dy;
+    int nchA = (kp.dy + 15) >> 4;                      // At chunks (16 rows each; rows >= dy are zero)
+
+    // column sums of M_ij * (dk/dx_j) [SE: of g*delta_d, scaled at the end], hyper-parameter sums
+    double colsum[4][3];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) colsum[jj][d] = 0.0;
+    double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
+
+    // staging: element e of this thread = chunk row 2e + (tid >> 7), column tid & 127 (0..63 I, 64..127 J):
+    // every wave-load is 512 contiguous bytes
+    int s_col = tid & 127, s_row0 = tid >> 7;
+    bool s_isJ = s_col >= 64;
+
+    for (int IB = JB; IB < TB; ++IB) {
+        int I = 4 * IB + wave;
+        bool active = I < T;
+        int scol = s_isJ ? (64 * JB + (s_col - 64)) : (64 * IB + s_col);
+        bool scol_ok = scol < mp;
+        int nchW = T - 4 * IB;
+        int nch = nchA + nchW;
+        d4 accA[4], accP[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { accA[jj] = d4{0, 0, 0, 0}; accP[jj] = d4{0, 0, 0, 0}; }
+        bool need[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) need[jj] = active && (J0 + jj <= I) && (J0 + jj < T);
+
+        double pre[8];
+        auto fetch = [&](int c) {
+            const double *src = (c < nchA) ? (At + (size_t)(16 * c + s_row0) * mp + scol)
+                                           : (W + (size_t)(16 * (4 * IB + (c - nchA)) + s_row0) * mp + scol);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pre[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+        };
+        auto stage = [&](double *buf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
+        };
+        // one staged chunk -> 16 tile products of this wave (operands prefetched into registers)
+        auto mma_chunk = [&](const double *buf, d4 (&acc)[4]) {
+            const double *rowp = buf + lg * G2_LD + lr;
+            double a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = rowp[(4 * s) * G2_LD + 16 * wave];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (need[jj]) {
+                    double b[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[s] = rowp[(4 * s) * G2_LD + 64 + 16 * jj];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[jj] = mfma(a[s], b[s], acc[jj]);
+                }
+            }
+        };
+        fetch(0);
+        for (int c = 0; c < nch; ++c) {
+            double *buf = chunk[c & 1];
+            stage(buf);
+            __syncthreads();
+            if (c + 1 < nch) fetch(c + 1);
+            if (!(ablate & 1)) {
+                if (c < nchA) {
+                    if (active) mma_chunk(buf, accA);
+                } else {
+                    int kt = 4 * IB + (c - nchA);
+                    if (active && kt >= I) mma_chunk(buf, accP);
+                }
+            }
+        }
+        __syncthreads();   // the next block's first staging write reuses chunk[0]
+        // ---- epilogue of block (IB, JB) for this wave's row tile ----
+        if (active && !(ablate & 2)) {
+            double rowsum[4][3];
+            double xi[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int i = 16 * I + lg + 4 * q;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    rowsum[q][d] = 0.0;
+                    xi[q][d] = Xu[(size_t)i * XPAD + d];
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (!need[jj]) continue;
+                int J = J0 + jj;
+                bool offdiag = I > J;
+                int j = 16 * J + lr;
+                double wgt = offdiag ? 2.0 : 1.0;
+                double xjv[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xjv[d] = Xu[(size_t)j * XPAD + d];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int i = 16 * I + lg + 4 * q;
+                    bool ok = (i < m) && (j < m);
+                    double Mij = ok ? (accA[jj][q] - dyd * accP[jj][q]) : 0.0;
+                    if constexpr (DIST == 0 && KERN == 0) {
+                        // SE: every derivative is (coordinate difference) x k x constant; constants applied at the end
+                        double kv;
+                        if (offdiag) kv = Kp[(size_t)(ok ? i : 0) * mp + (ok ? j : 0)];
+                        else kv = KernFn<0, 0>::value(kp, xi[q], xjv);
+                        double g = Mij * kv;
+                        gc_tr += (i == j) ? Mij : 0.0;
+                        gc_sv += wgt * g;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            double delta = xjv[d] - xi[q][d];
+                            double gd = g * delta;
+                            colsum[jj][d] += gd;
+                            rowsum[q][d] -= offdiag ? gd : 0.0;
+                            gc_l[d] += wgt * gd * delta;
+                        }
+                    } else {
+                        if (ok) {
+                            double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
+                            double k = KernFn<DIST, KERN>::pair(kp, xi[q], xjv, false, 0.0, dkdxi, dkdxj, dkdl);
+                            if (i != j) {
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) {
+                                    colsum[jj][d] += Mij * dkdxj[d];
+                                    if (offdiag) rowsum[q][d] += Mij * dkdxi[d];
+                                }
+                            } else {
+                                gc_tr += Mij;
+                            }
+                            gc_sv += wgt * Mij * k;
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) gc_l[d] += wgt * Mij * dkdl[d];
+                        }
+                    }
+                }
+            }
+            // row sums: over the 16 columns of the lane group, then lane lr == d stores component d
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double rs[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    rs[d] = row16_sum(rowsum[q][d]);
+                    if constexpr (DIST == 0 && KERN == 0) rs[d] *= -2.0 / (kp.ls[d] * kp.ls[d]);
+                }
+                if (lr < 3) {
+                    double v = (lr == 0) ? rs[0] : ((lr == 1) ? rs[1] : rs[2]);
+                    pl.rowpart[((roff + 16 * I + lg + 4 * q) * MAX_TB + JB) * XPAD + lr] = v;
+                }
+            }
+        }
+    }
+    // ---- column sums: over the 4 lane groups, then over the 4 waves ----
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double v = colsum[jj][d];
+            if constexpr (DIST == 0 && KERN == 0) v *= -2.0 / (kp.ls[d] * kp.ls[d]);
+            v += shfl_xor_d(v, 16);
+            v += shfl_xor_d(v, 32);
+            if (lg == 0) red[wave][16 * jj + lr][d] = v;
+        }
+    if constexpr (DIST == 0 && KERN == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gc_l[d] *= 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]);
+    }
+    double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
+    }
+    __syncthreads();
+    {
+        int jc = tid >> 2, d = tid & 3;          // 64 columns x 4
+        int j = 64 * JB + jc;
+        if (j < mp) {
+            double v = 0.0;
+            if (d < 3) v = red[0][jc][d] + red[1][jc][d] + red[2][jc][d] + red[3][jc][d];
+            pl.gXu[(roff + j) * XPAD + d] = v;
+        }
+    }
+    if (tid < GC_SLOTS) {
+        double v = 0.0;
+        if (tid < 5) v = gcred[0][tid] + gcred[1][tid] + gcred[2][tid] + gcred[3][tid];
+        pl.gcpart[((size_t)u * ut.max_T + JB) * GC_SLOTS + tid] = v;
+    }
+}
+
+// gXu[row] += sum_{JB <= IB(row)} rowpart[row][JB]   (fixed order)
+__global__ void k_gx_finalize(UnitTab ut, Pools pl, int total_rows) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = idx >> 2, d = idx & 3;
+    if (row >= total_rows || d == 3) return;
+    int u = ut.row_unit[row];
+    int local = row - ut.row_off[u];
+    int IB = local >> 6;
+    double v = pl.gXu[(size_t)row * XPAD + d];
+    const double *rp = pl.rowpart + (size_t)row * MAX_TB * XPAD + d;
+    for (int JB = 0; JB <= IB; ++JB) v += rp[JB * XPAD];
+    pl.gXu[(size_t)row * XPAD + d] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Assembly (gprf.py:253-288): Bethe-weighted sums, deterministic gather (no float atomics).
 // block 0: ll and gradC; blocks >= 1: gradX, one thread per (point, coordinate).
 // out = [ll | gradX (n x dx) | gradC (2 + ndfn)]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
-                                                  int want_gx, int want_gc, double *out) {
+                                                  int want_gx, int want_gc, int gc_blocks, double *out) {
     int dx = kp.dx;
     if (blockIdx.x == 0) {
         __shared__ double red[256][6];
@@ -934,8 +1212,9 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
                 acc[0] += w * ll;
                 if (want_gc) {
                     int T = pad16(m) >> 4;
+                    int nJ = gc_blocks ? ((T + 3) >> 2) : T;   // k_grad2 writes one partial per 64-column block
                     double g[5] = {0, 0, 0, 0, 0};
-                    for (int J = 0; J < T; ++J) {
+                    for (int J = 0; J < nJ; ++J) {
                         const double *gp = pl.gcpart + ((size_t)u * ut.max_T + J) * GC_SLOTS;
                         for (int t = 0; t < 5; ++t) g[t] += gp[t];
                     }
@@ -993,17 +1272,17 @@ void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx,
 template <int D, int K>
 static void fill_t(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     int nt64 = (16 * ut.max_T + 63) / 64;
-    hipLaunchKernelGGL((k_fill<D, K>), dim3(nt64 * nt64, ut.n_units), dim3(256), 0, s, ut, p, kp, nt64);
+    hipLaunchKernelGGL((k_fill<D, K>), dim3(nt64 * nt64, ut.n_ids), dim3(256), 0, s, ut, p, kp, nt64);
 }
 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
-    if (ut.n_units == 0 || ut.max_T == 0) return;
+    if (ut.n_ids == 0 || ut.max_T == 0) return;
     if (dist_id == 0 && kern_id == 0) fill_t<0, 0>(ut, p, kp, s);
     else fill_t<1, 1>(ut, p, kp, s);
 }
 
 void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
-    if (ut.n_units == 0) return;
+    if (ut.n_ids == 0) return;
     size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -1017,36 +1296,53 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
             (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             lds2_set = lds2;
         }
-        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_units), dim3(POTRF_WAVES * 64), lds2, s, ut, p);
+        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2, s, ut, p);
         return;
     }
-    hipLaunchKernelGGL(k_potrf, dim3(ut.n_units), dim3(POTRF_WAVES * 64), lds, s, ut, p);
+    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p);
 }
 
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
-    if (ut.n_units == 0) return;
+    if (ut.n_ids == 0) return;
     if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
-        dim3 grid((ut.max_T + 4 + 3) / 4, ut.n_units);
+        dim3 grid((ut.max_T + 4 + 3) / 4, ut.n_ids);
         if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
         else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
         return;
     }
-    hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_units), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
+    hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_ids), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
 }
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
-    if (ut.n_units == 0 || ut.max_T == 0) return;
+    if (ut.n_ids == 0 || ut.max_T == 0) return;
     if (!variant_flag("GPRF_AT_V1")) {
-        hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_units), dim3(256), 0, s, ut, p);
+        hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_ids), dim3(256), 0, s, ut, p);
         return;
     }
-    hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_units), dim3(256), 0, s, ut, p);
+    hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_ids), dim3(256), 0, s, ut, p);
+}
+
+bool grad_uses_blocks() { return !variant_flag("GPRF_GRAD_V1"); }
+
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s) {
+    if (!grad_uses_blocks() || total_rows == 0) return;
+    hipLaunchKernelGGL(k_gx_finalize, dim3((total_rows * 4 + 255) / 256), dim3(256), 0, s, ut, p, total_rows);
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 hipStream_t s) {
-    if (ut.n_units == 0 || ut.max_T == 0) return;
-    dim3 grid(ut.max_T, ut.n_units);
+                 int total_rows, hipStream_t s) {
+    if (ut.n_ids == 0 || ut.max_T == 0) return;
+    if (grad_uses_blocks()) {
+        dim3 grid2((ut.max_T + 3) / 4, ut.n_ids);
+        const char *ab = getenv("GPRF_GRAD_ABLATE");   // timing experiments only (results are wrong)
+        int ablate = ab ? atoi(ab) : 0;
+        if (dist_id == 0 && kern_id == 0)
+            hipLaunchKernelGGL((k_grad2<0, 0>), grid2, dim3(256), 0, s, ut, p, kp, want_gc, ablate);
+        else
+            hipLaunchKernelGGL((k_grad2<1, 1>), grid2, dim3(256), 0, s, ut, p, kp, want_gc, ablate);
+        return;
+    }
+    dim3 grid(ut.max_T, ut.n_ids);
     if (dist_id == 0 && kern_id == 0)
         hipLaunchKernelGGL((k_grad<0, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
     else
@@ -1057,7 +1353,8 @@ void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, c
                      int want_gx, int want_gc, double *out, hipStream_t s) {
     long work = (long)n * kp.dx;
     int blocks = 1 + (int)((work + 255) / 256);
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc,
+                       grad_uses_blocks() ? 1 : 0, out);
 }
 
 }  // namespace gprf
