@@ -42,6 +42,17 @@ __device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl
 
 __device__ __forceinline__ int pad16(int m) { return (m + 15) & ~15; }
 
+// XCD-aware 1-D grid -> (unit slot, part): workgroups are dealt round-robin over the 8 XCDs (each with its own
+// 4 MiB L2), so all `nparts` workgroups of one unit are given linear ids that are equal mod 8: they land on one
+// XCD and the unit's matrices are pulled from HBM once.  Launch with xcd_grid(n_ids, nparts) workgroups.
+__device__ __forceinline__ bool xcd_map(int linear, int n_ids, int nparts, int *slot, int *part) {
+    int grp = linear / (8 * nparts);
+    int rem = linear - grp * (8 * nparts);
+    *part = rem >> 3;
+    *slot = 8 * grp + (rem & 7);
+    return *slot < n_ids;
+}
+
 // ------------------------------------------------------------------------------------------------
 // distance / covariance functions (treegp side of gprf.py:333-375; definitions SURVEY.md §8a)
 // ------------------------------------------------------------------------------------------------
@@ -941,7 +952,8 @@ __global__ __launch_bounds__(256) void k_grad(UnitTab ut, Pools pl, KParams kp, 
 // runs over 16-row chunks of the stacked operand [At ; W] (both row-major with leading dimension mp):
 // a chunk's 64 I-columns and 64 J-columns are staged once in LDS (double buffered, one barrier per chunk)
 // and feed all 16 tile products of the block: wave w owns row tile I = 4 IB + w against the four J tiles
-// (1 A read + 4 B reads per 4 MFMAs).  M = At^T At - dy W^T W is symmetric and so is k, hence a strictly
+// (1 A read + 4 B reads per 4 MFMAs; W chunks first, the accumulators are then scaled by -dy and the At
+// chunks continue in the same registers).  M = At^T At - dy W^T W is symmetric and so is k, hence a strictly
 // lower tile (I > J) contributes its column sums to gradX of the J points AND its row sums to gradX of the I
 // points (and twice to the hyper-parameter sums); its k values are read back from the strictly-lower part of
 // the K/U pool, which the Cholesky never touches — only diagonal tiles re-evaluate exp().
@@ -967,11 +979,12 @@ __global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams 
     __shared__ double chunk[2][16 * G2_LD];
     __shared__ double red[4][64][4];
     __shared__ double gcred[4][8];
-    int u = ut.ids[blockIdx.y];
+    int slot, JB;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 3) >> 2, &slot, &JB)) return;
+    int u = ut.ids[slot];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int TB = (T + 3) >> 2;
-    int JB = blockIdx.x;
     if (JB >= TB) return;
     int tid = threadIdx.x;
     int lane = tid & 63, wave = tid >> 6;
@@ -1003,28 +1016,33 @@ __global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams 
         bool active = I < T;
         int scol = s_isJ ? (64 * JB + (s_col - 64)) : (64 * IB + s_col);
         bool scol_ok = scol < mp;
-        int nchW = T - 4 * IB;
-        int nch = nchA + nchW;
-        d4 accA[4], accP[4];
+        int nchW = T - 4 * IB;                 // W chunks kt = 4 IB .. T-1 come FIRST, then the At chunks
+        int nch = nchW + nchA;
+        d4 acc[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { accA[jj] = d4{0, 0, 0, 0}; accP[jj] = d4{0, 0, 0, 0}; }
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = d4{0, 0, 0, 0};
         bool need[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) need[jj] = active && (J0 + jj <= I) && (J0 + jj < T);
 
-        double pre[8];
-        auto fetch = [&](int c) {
-            const double *src = (c < nchA) ? (At + (size_t)(16 * c + s_row0) * mp + scol)
-                                           : (W + (size_t)(16 * (4 * IB + (c - nchA)) + s_row0) * mp + scol);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pre[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+        // two register sets: chunk c+1 and c+2 are in flight while chunk c is multiplied
+        double pre0[8], pre1[8];
+        auto src_of = [&](int c) -> const double * {
+            return (c < nchW) ? (W + (size_t)(16 * (4 * IB + c) + s_row0) * mp + scol)
+                              : (At + (size_t)(16 * (c - nchW) + s_row0) * mp + scol);
         };
-        auto stage = [&](double *buf) {
+        auto fetch0 = [&](int c) {
+            const double *src = src_of(c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
+            for (int e = 0; e < 8; ++e) pre0[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
         };
-        // one staged chunk -> 16 tile products of this wave (operands prefetched into registers)
-        auto mma_chunk = [&](const double *buf, d4 (&acc)[4]) {
+        auto fetch1 = [&](int c) {
+            const double *src = src_of(c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+        };
+        // one staged chunk -> 16 tile products of this wave
+        auto mma_chunk = [&](const double *buf) {
             const double *rowp = buf + lg * G2_LD + lr;
             double a[4];
 #pragma unroll
@@ -1040,20 +1058,32 @@ __global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams 
                 }
             }
         };
-        fetch(0);
-        for (int c = 0; c < nch; ++c) {
+        auto step = [&](int c, double (&pre)[8], bool refill_even) {
             double *buf = chunk[c & 1];
-            stage(buf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
             __syncthreads();
-            if (c + 1 < nch) fetch(c + 1);
+            if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
             if (!(ablate & 1)) {
-                if (c < nchA) {
-                    if (active) mma_chunk(buf, accA);
+                if (c < nchW) {
+                    if (active && (4 * IB + c) >= I) mma_chunk(buf);
                 } else {
-                    int kt = 4 * IB + (c - nchA);
-                    if (active && kt >= I) mma_chunk(buf, accP);
+                    if (c == nchW) {
+                        // acc held sum W^T W = (K^-1)_IJ so far: M = -dy K^-1 + A A^T continues in the same registers
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[jj][q] *= -dyd;
+                    }
+                    if (active) mma_chunk(buf);
                 }
             }
+        };
+        fetch0(0);
+        if (nch > 1) fetch1(1);
+        for (int c = 0; c < nch; c += 2) {
+            step(c, pre0, true);
+            if (c + 1 < nch) step(c + 1, pre1, false);
         }
         __syncthreads();   // the next block's first staging write reuses chunk[0]
         // ---- epilogue of block (IB, JB) for this wave's row tile ----
@@ -1083,7 +1113,7 @@ __global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams 
                 for (int q = 0; q < 4; ++q) {
                     int i = 16 * I + lg + 4 * q;
                     bool ok = (i < m) && (j < m);
-                    double Mij = ok ? (accA[jj][q] - dyd * accP[jj][q]) : 0.0;
+                    double Mij = ok ? acc[jj][q] : 0.0;
                     if constexpr (DIST == 0 && KERN == 0) {
                         // SE: every derivative is (coordinate difference) x k x constant; constants applied at the end
                         double kv;
@@ -1254,6 +1284,8 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // launchers
 // ------------------------------------------------------------------------------------------------
 // A/B switches for kernel generations (bring-up and interleaved timing only): env var set and != "0".
+static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
+
 static bool variant_flag(const char *name) {
     const char *v = getenv(name);
     return v && v[0] && v[0] != '0';
@@ -1333,7 +1365,7 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
                  int total_rows, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     if (grad_uses_blocks()) {
-        dim3 grid2((ut.max_T + 3) / 4, ut.n_ids);
+        dim3 grid2(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4));
         const char *ab = getenv("GPRF_GRAD_ABLATE");   // timing experiments only (results are wrong)
         int ablate = ab ? atoi(ab) : 0;
         if (dist_id == 0 && kern_id == 0)
