@@ -163,6 +163,7 @@ KParams make_kparams(gprf_ctx *c) {
     k.nv = c->theta[0];
     k.sv = c->theta[1];
     for (int i = 0; i < 3; ++i) k.ls[i] = (i < c->ndfn) ? c->theta[2 + i] : 1.0;
+    for (int i = 0; i < 3; ++i) k.inv_ls[i] = 1.0 / k.ls[i];
     k.dx = c->dx;
     k.ndfn = c->ndfn;
     k.dy = c->dy;

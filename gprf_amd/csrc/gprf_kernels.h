@@ -18,6 +18,7 @@ constexpr int MAX_TB = MAX_T / 4;   // 64-point blocks per unit edge (k_grad2's 
 struct KParams {
     double nv, sv;
     double ls[3];
+    double inv_ls[3];   // 1 / ls[d], rounded once on the host
     int dx, ndfn, dy;
 };
 

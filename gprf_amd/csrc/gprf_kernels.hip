@@ -63,17 +63,19 @@ constexpr double SQRT3 = 1.7320508075688772935;
 template <int DIST, int KERN>
 struct KernFn;
 
-// ("euclidean","se"):  d = sqrt(sum(((a-b)/l)^2)),  k = sv exp(-d*d)
+// ("euclidean","se"):  r^2 = sum(((a-b)/l)^2),  k = sv exp(-r^2).
+// treegp forms d = sqrt(r^2) with a divide per coordinate and then exp(-d*d); here the scaled differences use the
+// host-rounded reciprocal lengthscales and r^2 goes straight into exp: at most ~2 ulp apart in the exponent's
+// argument (relative 2e-16 * r^2 in k), the same size as the exp implementations' own disagreement.
 template <>
 struct KernFn<0, 0> {
     __device__ static __forceinline__ double value(const KParams &p, const double *xi, const double *xj) {
         double sq = 0.0;
         for (int d = 0; d < p.dx; ++d) {
-            double diff = (xi[d] - xj[d]) / p.ls[d];
+            double diff = (xi[d] - xj[d]) * p.inv_ls[d];
             sq += diff * diff;
         }
-        double r = sqrt(sq);
-        return p.sv * exp(-1.0 * r * r);
+        return p.sv * exp(-sq);
     }
     // k, d k(xj, xi)/d xj[d], d k / d ls[t]
     __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
@@ -238,6 +240,67 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, 
             v = (row == col) ? 1.0 : 0.0;
         }
         U[(size_t)row * mp + col] = v;
+    }
+}
+
+
+// k_fill2: the same fill by symmetry — one workgroup per 64x64 tile pair (ti <= tj): evaluates the tile once
+// (lane = column: 512-B wave stores), mirrors it through LDS and writes the transposed tile with the same
+// coalescing.  Halves the exp() work; the bytes written stay 8 mp^2 per unit.
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256) void k_fill2(UnitTab ut, Pools pl, KParams kp) {
+    __shared__ double xr[64 * XPAD];
+    __shared__ double tb[64 * 65];
+    int u = ut.ids[blockIdx.y];
+    int m = ut.m[u];
+    int mp = pad16(m);
+    int nt = (mp + 63) >> 6;
+    int pidx = blockIdx.x;
+    if (pidx >= nt * (nt + 1) / 2) return;
+    int ti = 0, rem = pidx;
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    int tj = ti + rem;
+    int r0 = ti * 64, c0 = tj * 64;
+    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
+    int t = threadIdx.x;
+    {
+        int rr = r0 + (t >> 2);
+        xr[t] = (rr < mp) ? Xu[(size_t)rr * XPAD + (t & 3)] : 0.0;
+    }
+    int cl = t & 63;
+    int col = c0 + cl;
+    double xj[XPAD];
+    for (int d = 0; d < XPAD; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XPAD + d] : 0.0;
+    __syncthreads();
+    double *U = pl.U + ut.mat_off[u];
+    double diag_add = kp.nv + ut.jitter[u];
+    int rbase = t >> 6;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        int rl = rbase + 4 * q;
+        int row = r0 + rl;
+        double v = 0.0;
+        if (row < mp && col < mp) {
+            if (row < m && col < m) {
+                v = KernFn<DIST, KERN>::value(kp, &xr[rl * XPAD], xj);
+                if (row == col) v += diag_add;
+            } else {
+                v = (row == col) ? 1.0 : 0.0;
+            }
+            U[(size_t)row * mp + col] = v;
+        }
+        tb[rl * 65 + cl] = v;
+    }
+    if (ti == tj) return;
+    __syncthreads();
+    // transposed tile: element [c0 + rr][r0 + l] = tile[l][rr]
+    int l = t & 63;
+    int tcol = r0 + l;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        int rr = rbase + 4 * q;
+        int trow = c0 + rr;
+        if (trow < mp && tcol < mp) U[(size_t)trow * mp + tcol] = tb[l * 65 + rr];
     }
 }
 
@@ -698,12 +761,14 @@ constexpr int SOLVE2_MAXT = 18;  // largest instantiation: 18 tiles x 8 VGPRs of
 
 template <int SOLVE2_MAXT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
-    int u = ut.ids[blockIdx.y];
+    int slot_, part_;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 4 + 3) >> 2, &slot_, &part_)) return;
+    int u = ut.ids[slot_];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int lr = lane & 15, lg = lane >> 4;
-    int cbx = blockIdx.x * 4 + wave;
+    int cbx = part_ * 4 + wave;
     bool is_y = cbx >= ut.max_T;
     int cb = is_y ? (cbx - ut.max_T) : cbx;
     if (is_y ? (cb >= 4) : (cb >= T)) return;
@@ -719,28 +784,29 @@ __global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
     const double *__restrict__ Yu = pl.Yu + roff * YPAD;
     int r0 = is_y ? 0 : cb;
 
+    // accumulator slot r = row tile r (slots above r0 stay unused): every wave of the workgroup walks the rows
+    // r = 0, 1, ... in the same order, so their reads of the U tiles of row r coincide in L1
     d4 acc[SOLVE2_MAXT];
 #pragma unroll
-    for (int t = 0; t < SOLVE2_MAXT; ++t) {
+    for (int r = 0; r < SOLVE2_MAXT; ++r) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double v = 0.0;
-            if (r0 + t < T) {
-                if (is_y) v = Yu[(size_t)(16 * (r0 + t) + lg + 4 * q) * YPAD + 16 * cb + lr];
-                else v = (t == 0 && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+            if (r >= r0 && r < T) {
+                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
+                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
             }
-            acc[t][q] = v;
+            acc[r][q] = v;
         }
     }
     double zz = 0.0;
 #pragma unroll
-    for (int t = 0; t < SOLVE2_MAXT; ++t) {
-        int r = r0 + t;
-        if (r < T) {
+    for (int r = 0; r < SOLVE2_MAXT; ++r) {
+        if (r >= r0 && r < T) {
             const double *Vr = V + (size_t)r * 256 + lg * 16 + lr;
             d4 w = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) w = mfma(Vr[64 * s], acc[t][s], w);
+            for (int s = 0; s < 4; ++s) w = mfma(Vr[64 * s], acc[r][s], w);
             if (is_y) {
                 double *zp = Z + (size_t)(16 * r + lg) * YPAD + 16 * cb + lr;
 #pragma unroll
@@ -753,16 +819,16 @@ __global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) wp[(size_t)(4 * q) * mp] = w[q];
             }
-            // rows below: acc_{r'} -= U_{r,r'}^T w   (tile (r, r') of U, r' = r0 + t2 > r)
-            const double *Ur = U + (size_t)(16 * r + lg) * mp + 16 * r0 + lr;
+            // rows below: acc_{r2} -= U_{r,r2}^T w   (tile (r, r2) of U, r2 > r)
+            const double *Ur = U + (size_t)(16 * r + lg) * mp + lr;
             const double *u0 = Ur, *u1 = Ur + (size_t)4 * mp, *u2 = Ur + (size_t)8 * mp, *u3 = Ur + (size_t)12 * mp;
 #pragma unroll
-            for (int t2 = t + 1; t2 < SOLVE2_MAXT; ++t2) {
-                if (r0 + t2 < T) {
-                    acc[t2] = mfma(-u0[16 * t2], w[0], acc[t2]);
-                    acc[t2] = mfma(-u1[16 * t2], w[1], acc[t2]);
-                    acc[t2] = mfma(-u2[16 * t2], w[2], acc[t2]);
-                    acc[t2] = mfma(-u3[16 * t2], w[3], acc[t2]);
+            for (int r2 = r + 1; r2 < SOLVE2_MAXT; ++r2) {
+                if (r2 < T) {
+                    acc[r2] = mfma(-u0[16 * r2], w[0], acc[r2]);
+                    acc[r2] = mfma(-u1[16 * r2], w[1], acc[r2]);
+                    acc[r2] = mfma(-u2[16 * r2], w[2], acc[r2]);
+                    acc[r2] = mfma(-u3[16 * r2], w[3], acc[r2]);
                 }
             }
         }
@@ -804,6 +870,66 @@ __global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[c][q];
+}
+
+
+// k_at3: At = Z^T W with one workgroup per 16 column tiles of the unit; wave w owns the column tiles
+// I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
+// DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
+// per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
+__global__ __launch_bounds__(256, 2) void k_at3(UnitTab ut, Pools pl) {
+    int slot_, part_;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    int u = ut.ids[slot_];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int I0 = 16 * part_;
+    if (I0 >= T) return;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    const double *__restrict__ Z = pl.Z + roff * YPAD;
+    double *__restrict__ At = pl.At + roff * YPAD;
+    d4 acc[4][4];   // [owned column tile][16-row block of At]
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = d4{0.0, 0.0, 0.0, 0.0};
+    int Imin = I0 + wave;
+    for (int kt = T - 1; kt >= I0; --kt) {
+        if (kt < Imin) continue;   // nothing of this wave's tiles reaches up here (keeps the waves in step)
+        const double *zp = Z + (size_t)(16 * kt + lg) * YPAD + lr;
+        double a[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[s][c] = zp[(size_t)(4 * s) * YPAD + 16 * c];
+        const double *wrow = W + (size_t)(16 * kt + lg) * mp + lr;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            int I = I0 + wave + 4 * o;
+            if (I <= kt && I < T) {
+                double b[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = wrow[(size_t)(4 * s) * mp + 16 * I];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[o][c] = mfma(a[s][c], b[s], acc[o][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        int I = I0 + wave + 4 * o;
+        if (I < T) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[o][c][q];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1309,6 +1435,13 @@ static void fill_t(const UnitTab &ut, const Pools &p, const KParams &kp, hipStre
 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
+    if (!variant_flag("GPRF_FILL_V1")) {
+        int nt = (16 * ut.max_T + 63) / 64;
+        dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
+        if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill2<0, 0>), grid, dim3(256), 0, s, ut, p, kp);
+        else hipLaunchKernelGGL((k_fill2<1, 1>), grid, dim3(256), 0, s, ut, p, kp);
+        return;
+    }
     if (dist_id == 0 && kern_id == 0) fill_t<0, 0>(ut, p, kp, s);
     else fill_t<1, 1>(ut, p, kp, s);
 }
@@ -1337,7 +1470,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
     if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
-        dim3 grid((ut.max_T + 4 + 3) / 4, ut.n_ids);
+        dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 4 + 3) / 4));
         if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
         else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
         return;
@@ -1348,7 +1481,10 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     if (!variant_flag("GPRF_AT_V1")) {
-        hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_ids), dim3(256), 0, s, ut, p);
+        if (variant_flag("GPRF_AT_V2"))
+            hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_ids), dim3(256), 0, s, ut, p);
+        else
+            hipLaunchKernelGGL(k_at3, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
         return;
     }
     hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_ids), dim3(256), 0, s, ut, p);
