@@ -873,6 +873,120 @@ __global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
 }
 
 
+// k_solve4: the same forward substitution with the U row panel of each step staged ONCE per workgroup in LDS
+// (cooperative, coalesced loads of panel r+1 overlap step r's MFMAs; one barrier per step), so the four waves
+// — four RHS column blocks — share every U tile and each update MFMA costs one conflict-free ds_read.
+// Accumulators stay in registers as in k_solve2.
+template <int MAXT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_solve4(UnitTab ut, Pools pl) {
+    constexpr int LDP = 16 * MAXT + 16;          // (LDP/16) odd: lane groups 32 banks apart
+    constexpr int NCH = (16 * MAXT + 63) / 64;
+    __shared__ double panel[2][16 * LDP];
+    __shared__ double Vl[2][256];
+    int slot_, part_;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 4 + 3) >> 2, &slot_, &part_)) return;
+    int u = ut.ids[slot_];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int tid = threadIdx.x;
+    int lane = tid & 63, wave = tid >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    int cbx = part_ * 4 + wave;
+    bool is_y = cbx >= ut.max_T;
+    int cb = is_y ? (cbx - ut.max_T) : cbx;
+    bool live = is_y ? (cb < 4) : (cb < T);      // dead waves still stage panels and hit the barriers
+    size_t roff = ut.row_off[u];
+    if (T == 0) {
+        if (live && is_y && lane == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
+        return;
+    }
+    // first row any wave of this workgroup needs
+    int rmin = (part_ * 4 + 3 >= ut.max_T) ? 0 : part_ * 4;
+    if (rmin >= T) return;                        // whole workgroup beyond this unit's columns (uniform)
+    const double *__restrict__ U = pl.U + ut.mat_off[u];
+    const double *__restrict__ V = pl.V + roff * 16;
+    double *__restrict__ W = pl.W + ut.mat_off[u];
+    double *__restrict__ Z = pl.Z + roff * YPAD;
+    const double *__restrict__ Yu = pl.Yu + roff * YPAD;
+    int r0 = is_y ? 0 : cb;
+
+    d4 acc[MAXT];
+#pragma unroll
+    for (int r = 0; r < MAXT; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = 0.0;
+            if (live && r >= r0 && r < T) {
+                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
+                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+            }
+            acc[r][q] = v;
+        }
+    }
+    // staging registers: wave w carries rows 4w..4w+3 of the panel, NCH column chunks of 64, plus one V entry
+    double pre[4][NCH], prev;
+    auto fetch = [&](int r) {
+        const double *Ur = U + (size_t)(16 * r + 4 * wave) * mp;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int col = 64 * k + lane;
+            bool ok = col >= 16 * (r + 1) && col < mp;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pre[rr][k] = ok ? Ur[(size_t)rr * mp + col] : 0.0;
+        }
+        prev = V[(size_t)r * 256 + tid];
+    };
+    fetch(rmin);
+    double zz = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXT; ++r) {
+        if (r >= rmin && r < T) {                 // uniform over the workgroup
+            double *buf = panel[r & 1];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                int col = 64 * k + lane;
+                if (col < LDP) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) buf[(4 * wave + rr) * LDP + col] = pre[rr][k];
+                }
+            }
+            Vl[r & 1][tid] = prev;
+            __syncthreads();
+            if (r + 1 < T) fetch(r + 1);
+            if (live && r >= r0) {
+                const double *vl = Vl[r & 1] + lg * 16 + lr;
+                d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) w = mfma(vl[64 * s], acc[r][s], w);
+                if (is_y) {
+                    double *zp = Z + (size_t)(16 * r + lg) * YPAD + 16 * cb + lr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        zp[(size_t)(4 * q) * YPAD] = w[q];
+                        zz += w[q] * w[q];
+                    }
+                } else {
+                    double *wp = W + (size_t)(16 * r + lg) * mp + 16 * cb + lr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wp[(size_t)(4 * q) * mp] = w[q];
+                }
+                const double *pr = buf + lg * LDP + lr;
+#pragma unroll
+                for (int r2 = r + 1; r2 < MAXT; ++r2) {
+                    if (r2 < T) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * r2], w[s], acc[r2]);
+                    }
+                }
+            }
+        }
+    }
+    if (live && is_y) {
+        for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
+        if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = zz;
+    }
+}
+
 // k_at3: At = Z^T W with one workgroup per 16 column tiles of the unit; wave w owns the column tiles
 // I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
@@ -1471,7 +1585,10 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
     if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
         dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 4 + 3) / 4));
-        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
+        if (ut.max_T <= 12 && !variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve4<12, 3>), grid, dim3(256), 0, s, ut, p);
+        else if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
+        else if (variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
+        else if (!variant_flag("GPRF_SOLVE_V2")) { hipLaunchKernelGGL((k_solve4<18, 2>), grid, dim3(256), 0, s, ut, p); return; }
         else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
         return;
     }
