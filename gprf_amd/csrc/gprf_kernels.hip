@@ -454,6 +454,27 @@ __global__ __launch_bounds__(POTRF_WAVES * 64) void k_potrf(UnitTab ut, Pools pl
 //   per wave at once, by the column operations that reduce U_jj to I;
 // * log|K| = 2 sum log U_kk (gpy_linalg.py:234) from the stored diagonal, in parallel, fixed order.
 // ------------------------------------------------------------------------------------------------
+// d = sqrt(p) and rd = 1/sqrt(p) from ONE Newton chain on the hardware reciprocal-square-root seed (the 16
+// pivots of a diagonal tile are a serial dependency: this halves the dependent instruction count of
+// sqrt() followed by 1.0/d).  p is a pivot of a kernel matrix, O(1e-8 .. 1e1): no range scaling needed.
+// d carries the usual final residual correction (correctly rounded except in rare halfway cases);
+// rd is accurate to ~1 ulp.
+__device__ __forceinline__ void sqrt_and_rsqrt(double p, double *d_out, double *rd_out) {
+    double y = __builtin_amdgcn_rsq(p);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        double t = p * y;
+        double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    double d = p * y;
+    double r = fma(-d, d, p);
+    d = fma(r, 0.5 * y, d);
+    double e2 = fma(-d, y, 1.0);
+    *rd_out = fma(e2, y, y);
+    *d_out = d;
+}
+
 // upper Cholesky of one 16x16 tile held one column per lane (s[i] = C[i][lr]); returns the first bad pivot
 // (1-based row within the tile) or 0; *dk / *rdk = this lane's diagonal entry and its reciprocal
 __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk, double *rdk) {
@@ -465,8 +486,8 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk
         bool isbad = !(pkk > 0.0);
         bad = (isbad && bad == 0) ? (k + 1) : bad;
         pkk = isbad ? 1.0 : pkk;
-        double d = sqrt(pkk);
-        double rd = 1.0 / d;
+        double d, rd;
+        sqrt_and_rsqrt(pkk, &d, &rd);
         double ukc = (lr > k) ? s[k] * rd : ((lr == k) ? d : 0.0);
         s[k] = ukc;
 #pragma unroll
@@ -479,7 +500,7 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk
     return bad;
 }
 
-__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pools pl, int ablate) {
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
         int ncol = 16 * ntr;
         for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
             int col = 16 * (j + 1) + c0 + lane;
-            if (c0 + lane < ncol) {
+            if (c0 + lane < ncol && !(ablate & 1)) {
                 double x[16];
                 double *Cc = U + (size_t)(16 * j) * mp + col;
 #pragma unroll
@@ -557,7 +578,9 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
             }
         }
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0 && (ablate & 2)) {
+            if (lane < 16) { rdt[lr] = 1.0; dvals[16 * (j + 1) + lr] = 1.0; }
+        } else if (wave == 0) {
             // look-ahead: tile (j+1, j+1) -> LDS (row-major) -> one column per lane -> factor
             int i = j + 1;
             const double *Cii = U + (size_t)(16 * i + lg) * mp + 16 * i + lr;
@@ -578,24 +601,46 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
             int bad = diag_factor16(s, lr, &dk, &rdk);
             publish(s, dk, rdk, i, bad);
         } else {
-            // trailing update without tile (j+1,j+1): tiles (i,k), j < i <= k < T, linear index t >= 1
+            // trailing update without tile (j+1,j+1): tiles (i,k), j < i <= k < T, linear index t >= 1;
+            // the next tile's C values are in flight while the current tile's MFMAs run
             int ntile = ntr * (ntr + 1) / 2;
-            for (int t = wave; t < ntile; t += POTRF_WAVES - 1) {
+            auto decode = [&](int t, int *ii, int *kk) {
                 int a_ = 0, rem = t;
                 while (rem >= ntr - a_) { rem -= ntr - a_; ++a_; }
-                int i = j + 1 + a_, k = i + rem;
+                *ii = j + 1 + a_;
+                *kk = *ii + rem;
+            };
+            int t = wave;
+            if (t < ntile && !(ablate & 4)) {
+                int i, k;
+                decode(t, &i, &k);
                 double *Cik = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
-                d4 acc;
+                d4 cur;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = Cik[(size_t)(4 * q) * mp];
+                for (int q = 0; q < 4; ++q) cur[q] = Cik[(size_t)(4 * q) * mp];
+                while (true) {
+                    int tn = t + (POTRF_WAVES - 1);
+                    int in_ = 0, kn = 0;
+                    double *Cn = nullptr;
+                    d4 nxt = {0.0, 0.0, 0.0, 0.0};
+                    bool more = tn < ntile;
+                    if (more) {
+                        decode(tn, &in_, &kn);
+                        Cn = U + (size_t)(16 * in_ + lg) * mp + 16 * kn + lr;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
-                    double b = P[(4 * s + lg) * ldp + 16 * k + lr];
-                    acc = mfma(a, b, acc);
+                        for (int q = 0; q < 4; ++q) nxt[q] = Cn[(size_t)(4 * q) * mp];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
+                        double b = P[(4 * s + lg) * ldp + 16 * k + lr];
+                        cur = mfma(a, b, cur);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = cur[q];
+                    if (!more) break;
+                    t = tn; i = in_; k = kn; Cik = Cn; cur = nxt;
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = acc[q];
             }
         }
         __syncthreads();
@@ -606,7 +651,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     }
     // ---- V_jj = U_jj^-1 for every diagonal tile: 4 tiles per wave at a time, lane (lg, lr) = row lr of
     //      tile 4*grp + lg;  apply to I the column operations that reduce U_jj to I ----
-    for (int grp = wave; 4 * grp < T; grp += POTRF_WAVES) {
+    for (int grp = wave; 4 * grp < T && !(ablate & 8); grp += POTRF_WAVES) {
         int jt = 4 * grp + lg;
         double *Us = P + jt * 256;            // the panel buffer is free now: 256 T <= 16 ldp doubles
         if (jt < T) {
@@ -884,24 +929,24 @@ __global__ __launch_bounds__(256, WPS) void k_solve4(UnitTab ut, Pools pl) {
     __shared__ double panel[2][16 * LDP];
     __shared__ double Vl[2][256];
     int slot_, part_;
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 4 + 3) >> 2, &slot_, &part_)) return;
+    int nI = (ut.max_T + 3) >> 2;                // parts 0..nI-1: identity column blocks 4p+wave; part nI: Y blocks
+    if (!xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_)) return;
     int u = ut.ids[slot_];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int tid = threadIdx.x;
     int lane = tid & 63, wave = tid >> 6;
     int lr = lane & 15, lg = lane >> 4;
-    int cbx = part_ * 4 + wave;
-    bool is_y = cbx >= ut.max_T;
-    int cb = is_y ? (cbx - ut.max_T) : cbx;
-    bool live = is_y ? (cb < 4) : (cb < T);      // dead waves still stage panels and hit the barriers
+    bool is_y = part_ == nI;
+    int cb = is_y ? wave : (part_ * 4 + wave);
+    bool live = is_y || (cb < T);                // dead waves still stage panels and hit the barriers
     size_t roff = ut.row_off[u];
     if (T == 0) {
         if (live && is_y && lane == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
         return;
     }
     // first row any wave of this workgroup needs
-    int rmin = (part_ * 4 + 3 >= ut.max_T) ? 0 : part_ * 4;
+    int rmin = is_y ? 0 : part_ * 4;
     if (rmin >= T) return;                        // whole workgroup beyond this unit's columns (uniform)
     const double *__restrict__ U = pl.U + ut.mat_off[u];
     const double *__restrict__ V = pl.V + roff * 16;
@@ -1575,7 +1620,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
             (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             lds2_set = lds2;
         }
-        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2, s, ut, p);
+        const char *ab = getenv("GPRF_POTRF_ABLATE");   // timing experiments only (results are wrong)
+        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2, s, ut, p, ab ? atoi(ab) : 0);
         return;
     }
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p);
@@ -1585,10 +1631,11 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
     if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
         dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 4 + 3) / 4));
-        if (ut.max_T <= 12 && !variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve4<12, 3>), grid, dim3(256), 0, s, ut, p);
+        dim3 grid4(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
+        if (ut.max_T <= 12 && !variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve4<12, 3>), grid4, dim3(256), 0, s, ut, p);
         else if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
         else if (variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
-        else if (!variant_flag("GPRF_SOLVE_V2")) { hipLaunchKernelGGL((k_solve4<18, 2>), grid, dim3(256), 0, s, ut, p); return; }
+        else if (!variant_flag("GPRF_SOLVE_V2")) { hipLaunchKernelGGL((k_solve4<18, 2>), grid4, dim3(256), 0, s, ut, p); return; }
         else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
         return;
     }

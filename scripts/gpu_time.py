@@ -10,6 +10,17 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20, tag=""):
     X = rng.rand(n, 2); Y = rng.randn(n, dy)
     b = Blocker(grid_centers(nb)); blocks = b.block_clusters(X); nbrs = b.neighbors() if pairs else []
     g = GPRF(X, Y, None, GPCov([1.0], [lscale, lscale], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs)
+    if os.environ.get("RAW"):
+        # ablation runs produce garbage (possibly NOT_PD): time the raw C-ABI call and ignore the status
+        g._push_neighbors(nbrs)
+        ctx = g._ctx
+        ctx.eval(X, True, False)
+        ctx.set_timing(True, reset=True)
+        for _ in range(reps):
+            ctx.eval(X, True, False)
+        st = ctx.get_timing()
+        print("%s pairs=%d RAW: stages(us) %s" % (tag, len(nbrs), {k: round(v * 1e3, 1) for k, v in st.items() if k != "count"}))
+        g.close(); return
     g.llgrad(grad_X=True)
     ts0 = []
     for _ in range(reps):
