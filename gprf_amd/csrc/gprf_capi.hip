@@ -89,7 +89,7 @@ struct gprf_ctx {
     DevBuf<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_info, d_row_unit;
     DevBuf<int64_t> d_matoff, d_slot_ptr;
     DevBuf<double> d_weight, d_jitter, d_slot_w;
-    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart;
+    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_M;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
 
@@ -154,7 +154,7 @@ Pools make_pools(gprf_ctx *c) {
     Pools p;
     p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
-    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p;
+    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p; p.M = c->d_M.p;
     return p;
 }
 
@@ -304,6 +304,7 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_slot_w.reserve(slot_w.size() + 1));
     HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
+    HIP_TRY(c, c->d_M.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
     HIP_TRY(c, c->d_Xu.reserve((size_t)rows * XPAD + 1));
     HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));
@@ -508,7 +509,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
     c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
-    c->d_gcpart.release(); c->d_rowpart.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
+    c->d_gcpart.release(); c->d_rowpart.release(); c->d_M.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);

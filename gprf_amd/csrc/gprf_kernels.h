@@ -40,6 +40,7 @@ struct UnitTab {
 struct Pools {
     double *U;     // K, overwritten by its upper Cholesky factor (row-major mp x mp per unit)
     double *W;     // U^-T (lower triangular, row-major)
+    double *M;     // k_mtile: lower-triangle tiles of M = A A^T - dy K^-1 (row-major mp x mp per unit)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
     double *Xu;    // gathered unit coordinates, XPAD per padded row
     double *Yu;    // gathered unit outputs, YPAD per padded row (zero padded)

@@ -1709,6 +1709,282 @@ __global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_mtile + k_gred: k_grad2 split in two so that the MFMA half carries no reduction state (half the
+// registers -> twice the resident workgroups to hide the operand staging) and the reduction half is a
+// plain streaming kernel.
+// k_mtile: one workgroup per 64x64 block pair (IB >= JB) of one unit: M_IJ = At_I^T At_J - dy sum_k W_kI^T W_kJ
+// for its (up to) 16 lower-triangle tiles, staged exactly as in k_grad2 (diagonal blocks stage their 64
+// columns once), written to the M pool.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams kp) {
+    __shared__ double chunk[2][16 * G2_LD];
+    int TBm = (ut.max_T + 3) >> 2;
+    int slot, bp;
+    if (!xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp)) return;
+    int u = ut.ids[slot];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int TB = (T + 3) >> 2;
+    // block pair index -> (JB, IB >= JB), enumerated over the launch-wide TBm
+    int JB = 0, rem = bp;
+    while (rem >= TBm - JB) { rem -= TBm - JB; ++JB; }
+    int IB = JB + rem;
+    if (IB >= TB) return;
+    int tid = threadIdx.x;
+    int lane = tid & 63, wave = tid >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    const double *__restrict__ At = pl.At + roff * YPAD;
+    double *__restrict__ Mo = pl.M + ut.mat_off[u];
+    int J0 = 4 * JB;
+    int I = 4 * IB + wave;
+    bool active = I < T;
+    bool diagblk = IB == JB;
+    double dyd = (double)kp.dy;
+    int nchA = (kp.dy + 15) >> 4;
+    int nchW = T - 4 * IB;
+    int nch = nchW + nchA;
+
+    int s_col = tid & 127, s_row0 = tid >> 7;
+    bool s_isJ = s_col >= 64;
+    int scol = s_isJ ? (64 * JB + (s_col - 64)) : (64 * IB + s_col);
+    bool scol_ok = scol < mp && !(diagblk && s_isJ);      // a diagonal block reads its columns once
+    int boff = diagblk ? 0 : 64;                          // where the J columns sit in the staged row
+
+    d4 acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[jj] = d4{0, 0, 0, 0};
+    bool need[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) need[jj] = active && (J0 + jj <= I) && (J0 + jj < T);
+
+    double pre0[8], pre1[8];
+    auto src_of = [&](int c) -> const double * {
+        return (c < nchW) ? (W + (size_t)(16 * (4 * IB + c) + s_row0) * mp + scol)
+                          : (At + (size_t)(16 * (c - nchW) + s_row0) * mp + scol);
+    };
+    auto fetch0 = [&](int c) {
+        const double *src = src_of(c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre0[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+    };
+    auto fetch1 = [&](int c) {
+        const double *src = src_of(c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+    };
+    auto mma_chunk = [&](const double *buf) {
+        const double *rowp = buf + lg * G2_LD + lr;
+        double a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = rowp[(4 * s) * G2_LD + 16 * wave];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (need[jj]) {
+                double b[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = rowp[(4 * s) * G2_LD + boff + 16 * jj];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[jj] = mfma(a[s], b[s], acc[jj]);
+            }
+        }
+    };
+    auto step = [&](int c, double (&pre)[8], bool refill_even) {
+        double *buf = chunk[c & 1];
+        if (!(diagblk && s_isJ)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
+        }
+        __syncthreads();
+        if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
+        if (c < nchW) {
+            if (active && (4 * IB + c) >= I) mma_chunk(buf);
+        } else {
+            if (c == nchW) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[jj][q] *= -dyd;
+            }
+            if (active) mma_chunk(buf);
+        }
+    };
+    fetch0(0);
+    if (nch > 1) fetch1(1);
+    for (int c = 0; c < nch; c += 2) {
+        step(c, pre0, true);
+        if (c + 1 < nch) step(c + 1, pre1, false);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (need[jj]) {
+            double *mp_ = Mo + (size_t)(16 * I + lg) * mp + 16 * (J0 + jj) + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mp_[(size_t)(4 * q) * mp] = acc[jj][q];
+        }
+    }
+}
+
+// k_gred: workgroup = (unit, 64-column block JB), wave w owns the row tiles I = 4 IB + w of every block IB >= JB.
+// Streams the lower-triangle tiles of M and K (coalesced 128-B rows), accumulates column sums in registers
+// over the whole walk and writes row sums per block through rowpart, exactly like k_grad2's epilogue.
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256, 2) void k_gred(UnitTab ut, Pools pl, KParams kp, int want_gc) {
+    __shared__ double red[4][64][4];
+    __shared__ double gcred[4][8];
+    int slot, JB;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 3) >> 2, &slot, &JB)) return;
+    int u = ut.ids[slot];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int TB = (T + 3) >> 2;
+    if (JB >= TB) return;
+    int tid = threadIdx.x;
+    int lane = tid & 63, wave = tid >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ Mi = pl.M + ut.mat_off[u];
+    const double *__restrict__ Kp = pl.U + ut.mat_off[u];
+    const double *__restrict__ Xu = pl.Xu + roff * XPAD;
+    int J0 = 4 * JB;
+    double colsum[4][3];
+    double xjv[4][3];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int j = 16 * (J0 + jj) + lr;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            colsum[jj][d] = 0.0;
+            xjv[jj][d] = (j < mp) ? Xu[(size_t)j * XPAD + d] : 0.0;
+        }
+    }
+    double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
+    for (int IB = JB; IB < TB; ++IB) {
+        int I = 4 * IB + wave;
+        if (I >= T) continue;
+        double rowsum[4][3], xi[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = 16 * I + lg + 4 * q;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                rowsum[q][d] = 0.0;
+                xi[q][d] = Xu[(size_t)i * XPAD + d];
+            }
+        }
+        // all tile loads of this row tile first (up to 32 loads in flight), then the arithmetic
+        double Mv[4][4], Kv[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            int J = J0 + jj;
+            bool nd = (J <= I) && (J < T);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                size_t off = (size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr;
+                Mv[jj][q] = nd ? Mi[off] : 0.0;
+                Kv[jj][q] = (nd && I > J) ? Kp[off] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            int J = J0 + jj;
+            if (!((J <= I) && (J < T))) continue;
+            bool offdiag = I > J;
+            int j = 16 * J + lr;
+            double wgt = offdiag ? 2.0 : 1.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int i = 16 * I + lg + 4 * q;
+                bool ok = (i < m) && (j < m);
+                double Mij = ok ? Mv[jj][q] : 0.0;
+                if constexpr (DIST == 0 && KERN == 0) {
+                    double kv = offdiag ? Kv[jj][q] : KernFn<0, 0>::value(kp, xi[q], xjv[jj]);
+                    double g = Mij * kv;
+                    gc_tr += (i == j) ? Mij : 0.0;
+                    gc_sv += wgt * g;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        double delta = xjv[jj][d] - xi[q][d];
+                        double gd = g * delta;
+                        colsum[jj][d] += gd;
+                        rowsum[q][d] -= offdiag ? gd : 0.0;
+                        gc_l[d] += wgt * gd * delta;
+                    }
+                } else {
+                    if (ok) {
+                        double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
+                        double k = KernFn<DIST, KERN>::pair(kp, xi[q], xjv[jj], false, 0.0, dkdxi, dkdxj, dkdl);
+                        if (i != j) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                colsum[jj][d] += Mij * dkdxj[d];
+                                if (offdiag) rowsum[q][d] += Mij * dkdxi[d];
+                            }
+                        } else {
+                            gc_tr += Mij;
+                        }
+                        gc_sv += wgt * Mij * k;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gc_l[d] += wgt * Mij * dkdl[d];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double rs[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                rs[d] = row16_sum(rowsum[q][d]);
+                if constexpr (DIST == 0 && KERN == 0) rs[d] *= -2.0 / (kp.ls[d] * kp.ls[d]);
+            }
+            if (lr < 3) {
+                double v = (lr == 0) ? rs[0] : ((lr == 1) ? rs[1] : rs[2]);
+                pl.rowpart[((roff + 16 * I + lg + 4 * q) * MAX_TB + JB) * XPAD + lr] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double v = colsum[jj][d];
+            if constexpr (DIST == 0 && KERN == 0) v *= -2.0 / (kp.ls[d] * kp.ls[d]);
+            v += shfl_xor_d(v, 16);
+            v += shfl_xor_d(v, 32);
+            if (lg == 0) red[wave][16 * jj + lr][d] = v;
+        }
+    if constexpr (DIST == 0 && KERN == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gc_l[d] *= 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]);
+    }
+    double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
+    }
+    __syncthreads();
+    {
+        int jc = tid >> 2, d = tid & 3;
+        int j = 64 * JB + jc;
+        if (j < mp) {
+            double v = 0.0;
+            if (d < 3) v = red[0][jc][d] + red[1][jc][d] + red[2][jc][d] + red[3][jc][d];
+            pl.gXu[(roff + j) * XPAD + d] = v;
+        }
+    }
+    if (tid < GC_SLOTS) {
+        double v = 0.0;
+        if (tid < 5) v = gcred[0][tid] + gcred[1][tid] + gcred[2][tid] + gcred[3][tid];
+        pl.gcpart[((size_t)u * ut.max_T + JB) * GC_SLOTS + tid] = v;
+    }
+}
+
 // gXu[row] += sum_{JB <= IB(row)} rowpart[row][JB]   (fixed order)
 __global__ void k_gx_finalize(UnitTab ut, Pools pl, int total_rows) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1831,7 +2107,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    if (!variant_flag("GPRF_POTRF_V1") && !variant_flag("GPRF_POTRF_V2") && ut.max_T <= 17) {
+    if (variant_flag("GPRF_POTRF_V3") && ut.max_T <= 17) {
         int T = ut.max_T;
         size_t lds3 = (size_t)(16 * (16 * T + 16) + 256 + 16 + 16 * 17 + 16 * T) * sizeof(double) +
                       (size_t)(T * (T + 1) / 2) * sizeof(int);
@@ -1896,6 +2172,14 @@ void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipSt
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
                  int total_rows, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
+    if (grad_uses_blocks() && !variant_flag("GPRF_GRAD_V2")) {
+        int TBm = (ut.max_T + 3) / 4;
+        hipLaunchKernelGGL(k_mtile, dim3(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2)), dim3(256), 0, s, ut, p, kp);
+        dim3 gridr(xcd_grid(ut.n_ids, TBm));
+        if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_gred<0, 0>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
+        else hipLaunchKernelGGL((k_gred<1, 1>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
+        return;
+    }
     if (grad_uses_blocks()) {
         dim3 grid2(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4));
         const char *ab = getenv("GPRF_GRAD_ABLATE");   // timing experiments only (results are wrong)
