@@ -238,7 +238,7 @@ class Context(object):
 
     def debug_fetch(self, l, what):
         m, mp, _ = self.debug_unit_shape(l)
-        shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,)}[what]
+        shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,), 6: (8,)}[what]
         out = np.zeros(shape)
         self._check(self.lib.gprf_debug_fetch(self.h, l, what, dptr(out), out.size), "gprf_debug_fetch")
         return out

@@ -52,6 +52,7 @@ struct Pools {
     double *zzpart;   // per unit x 4 : partial sums of ||Z||_F^2 per Y column block
     double *gcpart;   // per unit x max_T x GC_SLOTS
     int32_t *info;    // per unit: 0 ok, k>0 = non-positive pivot at row k-1
+    double *dbg;      // per unit x 8: in-kernel cycle stamps of diagnostic builds (GPRF_POTRF_ABLATE & 16)
 };
 
 struct AssembleTab {

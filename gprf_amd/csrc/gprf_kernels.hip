@@ -42,6 +42,15 @@ __device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl
 
 __device__ __forceinline__ int pad16(int m) { return (m + 15) & ~15; }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
+// its outstanding global stores (vmcnt), which __syncthreads() would also drain (~1 us of store-acknowledge
+// latency per barrier on a loaded chip).  Use only where nothing written to global memory before the barrier
+// is read back inside the kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // XCD-aware 1-D grid -> (unit slot, part): workgroups are dealt round-robin over the 8 XCDs (each with its own
 // 4 MiB L2), so all `nparts` workgroups of one unit are given linear ids that are equal mod 8: they land on one
 // XCD and the unit's matrices are pulled from HBM once.  Launch with xcd_grid(n_ids, nparts) workgroups.
@@ -548,6 +557,16 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     }
     __syncthreads();
 
+    // diagnostic stamps (ablate & 16): cycles wave 0 spends in [row panel | barrier | factor | barrier]
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
+    bool stamp = (ablate & 16) && threadIdx.x == 0;
+#define GPRF_STAMP(k)                                                     \
+    if (stamp) {                                                          \
+        unsigned long long tn = __builtin_amdgcn_s_memtime();             \
+        tacc[k] += tn - tprev;                                            \
+        tprev = tn;                                                       \
+    }
+    if (stamp) tprev = __builtin_amdgcn_s_memtime();
     for (int j = 0; j < T; ++j) {
         if (s_fail) {
             if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
@@ -577,7 +596,9 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
                 }
             }
         }
+        GPRF_STAMP(0)
         __syncthreads();
+        GPRF_STAMP(1)
         if (wave == 0 && (ablate & 2)) {
             if (lane < 16) { rdt[lr] = 1.0; dvals[16 * (j + 1) + lr] = 1.0; }
         } else if (wave == 0) {
@@ -601,50 +622,47 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
             int bad = diag_factor16(s, lr, &dk, &rdk);
             publish(s, dk, rdk, i, bad);
         } else {
-            // trailing update without tile (j+1,j+1): tiles (i,k), j < i <= k < T, linear index t >= 1;
-            // the next tile's C values are in flight while the current tile's MFMAs run
-            int ntile = ntr * (ntr + 1) / 2;
-            auto decode = [&](int t, int *ii, int *kk) {
-                int a_ = 0, rem = t;
-                while (rem >= ntr - a_) { rem -= ntr - a_; ++a_; }
-                *ii = j + 1 + a_;
-                *kk = *ii + rem;
-            };
-            int t = wave;
-            if (t < ntile && !(ablate & 4)) {
-                int i, k;
-                decode(t, &i, &k);
-                double *Cik = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
-                d4 cur;
+            // trailing update without tile (j+1,j+1): tile rows i = j+1 .. T-1 dealt cyclically to waves 1..7; along
+            // a row the A operand (column block i of the panel) is read once, the pointer just advances by one
+            // tile, and the next tile's C values are in flight while the current tile's MFMAs run
+            if (!(ablate & 4)) {
+                for (int i = j + 1 + (wave - 1); i < T; i += POTRF_WAVES - 1) {
+                    double a[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cur[q] = Cik[(size_t)(4 * q) * mp];
-                while (true) {
-                    int tn = t + (POTRF_WAVES - 1);
-                    int in_ = 0, kn = 0;
-                    double *Cn = nullptr;
-                    d4 nxt = {0.0, 0.0, 0.0, 0.0};
-                    bool more = tn < ntile;
-                    if (more) {
-                        decode(tn, &in_, &kn);
-                        Cn = U + (size_t)(16 * in_ + lg) * mp + 16 * kn + lr;
+                    for (int s = 0; s < 4; ++s) a[s] = -P[(4 * s + lg) * ldp + 16 * i + lr];
+                    int k = (i == j + 1) ? i + 1 : i;
+                    if (k >= T) continue;
+                    double *Cik = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
+                    const double *Pk = P + lg * ldp + 16 * k + lr;
+                    d4 cur;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) nxt[q] = Cn[(size_t)(4 * q) * mp];
+                    for (int q = 0; q < 4; ++q) cur[q] = Cik[(size_t)(4 * q) * mp];
+                    for (; k < T; ++k) {
+                        d4 nxt = {0.0, 0.0, 0.0, 0.0};
+                        if (k + 1 < T) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) nxt[q] = Cik[(size_t)(4 * q) * mp + 16];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) cur = mfma(a[s], Pk[(4 * s) * ldp], cur);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = cur[q];
+                        Cik += 16;
+                        Pk += 16;
+                        cur = nxt;
                     }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
-                        double b = P[(4 * s + lg) * ldp + 16 * k + lr];
-                        cur = mfma(a, b, cur);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = cur[q];
-                    if (!more) break;
-                    t = tn; i = in_; k = kn; Cik = Cn; cur = nxt;
                 }
             }
         }
+        GPRF_STAMP(2)
         __syncthreads();
+        GPRF_STAMP(3)
     }
+    if (stamp) {
+        for (int k = 0; k < 4; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+        pl.dbg[(size_t)u * 8 + 4] = (double)T;
+    }
+#undef GPRF_STAMP
     if (s_fail) {
         if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
         return;
@@ -703,7 +721,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
 //   S4  wave 0 factors that tile (look-ahead) while waves 1..7 update the rest of their tiles from the panel
 // ------------------------------------------------------------------------------------------------
 template <int SLOTS>
-__global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pools pl, int ablate) {
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
@@ -764,7 +782,6 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pool
                     x[c] *= rdt[c];
 #pragma unroll
                     for (int a = c + 1; a < 16; ++a) x[a] -= Ud[c * 16 + a] * x[c];
-                    __builtin_amdgcn_sched_barrier(0);   // keep the broadcast reads of row c next to their use
                 }
                 double *Cc = U + (size_t)(16 * j) * mp + col;
 #pragma unroll
@@ -786,20 +803,39 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pool
             int bad = diag_factor16(s, lr, &dk, &rdk);
             publish(s, dk, rdk, 0, bad);
         }
+        unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+        bool stamp = (ablate & 16) && tid == 0;
+#define GPRF_STAMP(k)                                                     \
+        if (stamp) {                                                      \
+            unsigned long long tn = __builtin_amdgcn_s_memtime();         \
+            tacc[k] += tn - tprev;                                        \
+            tprev = tn;                                                   \
+        }
+        if (stamp) tprev = __builtin_amdgcn_s_memtime();
         for (int j = 0; j < T; ++j) {
-            __syncthreads();                                   // B1 (after S1)
+            lds_barrier();                                     // B1 (after S1)
+            GPRF_STAMP(0)
             if (s_fail) { failed = true; break; }
             if (T - j - 1 == 0) break;
             trsm_panel(j);                                     // S2
-            __syncthreads();                                   // B2
-            __syncthreads();                                   // B3 (after S3: tile (j+1,j+1) is in Tt)
+            GPRF_STAMP(1)
+            lds_barrier();                                     // B2
+            lds_barrier();                                     // B3 (after S3: tile (j+1,j+1) is in Tt)
+            GPRF_STAMP(2)
             double s[16], dk, rdk;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = Tt[r * 17 + lr];
             int bad = diag_factor16(s, lr, &dk, &rdk);
             publish(s, dk, rdk, j + 1, bad);                   // S4 (look-ahead factor)
-            __syncthreads();                                   // B4
+            GPRF_STAMP(3)
+            lds_barrier();                                     // B4
+            GPRF_STAMP(4)
         }
+        if (stamp) {
+            for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+            pl.dbg[(size_t)u * 8 + 5] = (double)T;
+        }
+#undef GPRF_STAMP
     } else {
         d4 acc[SLOTS];
         int ik[SLOTS];
@@ -819,20 +855,24 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pool
             }
         }
         for (int j = 0; j < T; ++j) {
+            // per-iteration opaque copy of the lane's column: keeps the 22 x 8 LDS tile addresses from being
+            // hoisted out of the loop (they would occupy as many registers as the accumulators)
+            int lrv = lr, lgv = lg;
+            asm volatile("" : "+v"(lrv), "+v"(lgv));
             // ---- S1: row-j tiles -> LDS panel ----
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 int i = ik[sl] >> 8, k = ik[sl] & 255;
                 if (i == j && k > j) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) P[(lg + 4 * q) * ldp + 16 * k + lr] = acc[sl][q];
+                    for (int q = 0; q < 4; ++q) P[(lgv + 4 * q) * ldp + 16 * k + lrv] = acc[sl][q];
                 }
             }
-            __syncthreads();                                   // B1
+            lds_barrier();                                     // B1
             if (s_fail) { failed = true; break; }
             if (T - j - 1 == 0) break;
             trsm_panel(j);                                     // S2
-            __syncthreads();                                   // B2
+            lds_barrier();                                     // B2
             // ---- S3: the owner of (j+1, j+1) updates it first and hands it over ----
             int jn = j + 1;
 #pragma unroll
@@ -840,14 +880,14 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pool
                 if (ik[sl] == ((jn << 8) | jn)) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        double a = P[(4 * s + lg) * ldp + 16 * jn + lr];
+                        double a = P[(4 * s + lgv) * ldp + 16 * jn + lrv];
                         acc[sl] = mfma(-a, a, acc[sl]);
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Tt[(lg + 4 * q) * 17 + lr] = acc[sl][q];
+                    for (int q = 0; q < 4; ++q) Tt[(lgv + 4 * q) * 17 + lrv] = acc[sl][q];
                 }
             }
-            __syncthreads();                                   // B3
+            lds_barrier();                                     // B3
             // ---- S4: trailing update of everything else this wave owns ----
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
@@ -855,13 +895,13 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pool
                 if (i > j && i < 255 && !(i == jn && k == jn)) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
-                        double b = P[(4 * s + lg) * ldp + 16 * k + lr];
+                        double a = -P[(4 * s + lgv) * ldp + 16 * i + lrv];
+                        double b = P[(4 * s + lgv) * ldp + 16 * k + lrv];
                         acc[sl] = mfma(a, b, acc[sl]);
                     }
                 }
             }
-            __syncthreads();                                   // B4: P, Ud, rdt are free for the next step
+            lds_barrier();                                     // B4: P, Ud, rdt are free for the next step
         }
     }
     if (failed || s_fail) {
@@ -2117,8 +2157,10 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
             (void)hipFuncSetAttribute((const void *)k_potrf3<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             lds3_set = lds3;
         }
-        if (T <= 12) hipLaunchKernelGGL((k_potrf3<12>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p);
-        else hipLaunchKernelGGL((k_potrf3<22>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p);
+        const char *ab3 = getenv("GPRF_POTRF_ABLATE");
+        int abl3 = ab3 ? atoi(ab3) : 0;
+        if (T <= 12) hipLaunchKernelGGL((k_potrf3<12>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p, abl3);
+        else hipLaunchKernelGGL((k_potrf3<22>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p, abl3);
         return;
     }
     if (!variant_flag("GPRF_POTRF_V1")) {
@@ -2129,7 +2171,13 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
             lds2_set = lds2;
         }
         const char *ab = getenv("GPRF_POTRF_ABLATE");   // timing experiments only (results are wrong)
-        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2, s, ut, p, ab ? atoi(ab) : 0);
+        const char *pad = getenv("GPRF_POTRF_LDSPAD");  // experiment: extra LDS to lower the residency
+        size_t lds2p = lds2 + (pad ? (size_t)atoi(pad) : 0);
+        if (lds2p > 48 * 1024 && lds2p > lds2_set) {
+            (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p);
+            lds2_set = lds2p;
+        }
+        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2p, s, ut, p, ab ? atoi(ab) : 0);
         return;
     }
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p);

@@ -1,0 +1,24 @@
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["GPRF_POTRF_ABLATE"] = "16"
+from gprf_amd import GPCov, Blocker, grid_centers
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(1)
+n = 10000; X = rng.rand(n, 2); Y = rng.randn(n, 50)
+b = Blocker(grid_centers(100)); blocks = b.block_clusters(X); nbrs = b.neighbors()
+g = GPRF(X, Y, None, GPCov([1.0], [0.06, 0.06], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs)
+g._push_neighbors(nbrs)
+ctx = g._ctx
+for _ in range(3): ctx.debug_run(X, 1)
+nt, nl = ctx.num_units()
+rows = np.array([ctx.debug_fetch(l, 6) for l in range(nl)])
+v3 = bool(os.environ.get("GPRF_POTRF_V3"))
+tc = 5 if v3 else 4
+for T in (7, 13, 17):
+    sel = rows[rows[:, tc] == T]
+    if len(sel):
+        m = sel[:, :tc].mean(axis=0)
+        names = ["B1wait", "panel", "B2+B3wait", "factor", "B4wait"] if v3 else ["panel", "barrier1", "factor", "barrier2"]
+        print("T=%d units=%d cycles/step:" % (T, len(sel)), " ".join("%s %.0f" % (a, b) for a, b in zip(names, m / (T - 1))),
+              " total/step %.0f" % (m.sum() / (T - 1)))
