@@ -31,6 +31,8 @@ SIGNATURES = {
     "gprf_set_theta": (ctypes.c_int, [_vp, _dp, _i32]),
     "gprf_set_blocks": (ctypes.c_int, [_vp, _i32, _i64p, _i32p]),
     "gprf_set_neighbors": (ctypes.c_int, [_vp, _i32, _i32p]),
+    "gprf_nearest_center": (ctypes.c_int, [_i32, _i32, _dp, _i32, _dp, _i32p]),
+    "gprf_set_block_assignment": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
     "gprf_partition_units": (ctypes.c_int, [_i32, _i32p, _i32, _i32, _i32p]),
     "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
@@ -120,6 +122,17 @@ def dptr(a):
     return a.ctypes.data_as(_dp)
 
 
+def nearest_center(X, centers):
+    """block id of every point (gprf_nearest_center; host only)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    C = np.ascontiguousarray(centers, dtype=np.float64)
+    out = np.empty(X.shape[0], dtype=np.int32)
+    rc = load().gprf_nearest_center(X.shape[0], X.shape[1], dptr(X), C.shape[0], dptr(C), out.ctypes.data_as(_i32p))
+    if rc != GPRF_OK:
+        raise GprfHipError("gprf_nearest_center failed (%d)" % rc)
+    return out
+
+
 class Context(object):
     """Thin RAII wrapper over gprf_ctx*."""
 
@@ -164,6 +177,12 @@ class Context(object):
         point_idx = np.ascontiguousarray(point_idx, dtype=np.int32)
         self._check(self.lib.gprf_set_blocks(self.h, len(block_ptr) - 1, block_ptr.ctypes.data_as(_i64p),
                                              point_idx.ctypes.data_as(_i32p)), "gprf_set_blocks")
+
+    def set_block_assignment(self, n_blocks, block_of):
+        block_of = np.ascontiguousarray(block_of, dtype=np.int32)
+        assert block_of.shape == (self.n,)
+        self._check(self.lib.gprf_set_block_assignment(self.h, int(n_blocks), block_of.ctypes.data_as(_i32p)),
+                    "gprf_set_block_assignment")
 
     def set_neighbors(self, pairs):
         pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))

@@ -28,6 +28,13 @@ class Blocker(object):
         with np.errstate(invalid="ignore"):
             return np.argmin(pair_distances(X, self.block_centers), axis=1)
 
+    def block_assignment_fast(self, X):
+        """Same assignment through the C library's host helper (gprf_nearest_center): the reference's radicand
+        and tie rule in plain double arithmetic instead of numpy temporaries + BLAS.  Can differ from
+        ``block_assignment`` only for a point whose two nearest centres are equidistant to the last bit."""
+        from . import _capi
+        return _capi.nearest_center(X, self.block_centers)
+
     def block_clusters(self, X):
         """block_clustering.py:17-26 -> list of index arrays, ascending inside each block."""
         blocks = self.block_assignment(X)

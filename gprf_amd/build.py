@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
            "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gprf_hip.h"
@@ -572,6 +573,75 @@ int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, con
     c->have_blocks = true;
     c->units_dirty = true;
     return GPRF_OK;
+}
+
+int gprf_nearest_center(int32_t n, int32_t dx, const double *X, int32_t nc, const double *centers,
+                        int32_t *block_of) {
+    if (n < 0 || dx < 1 || dx > 8 || nc < 1 || !X || !centers || !block_of) return GPRF_ERR_ARG;
+    // centres as structure-of-arrays so that the radicand loop vectorises
+    std::vector<double> c2(nc), cs((size_t)dx * nc);
+    for (int k = 0; k < nc; ++k) {
+        double s = 0.0;
+        for (int d = 0; d < dx; ++d) {
+            double v = centers[(size_t)k * dx + d];
+            cs[(size_t)d * nc + k] = v;
+            s += v * v;
+        }
+        c2[k] = s;
+    }
+    auto work = [&](int p0, int p1) {
+        std::vector<double> r(nc);
+        for (int p = p0; p < p1; ++p) {
+            const double *x = X + (size_t)p * dx;
+            double x2 = 0.0;
+            for (int d = 0; d < dx; ++d) x2 += x[d] * x[d];
+            for (int k = 0; k < nc; ++k) r[k] = 0.0;
+            for (int d = 0; d < dx; ++d) {
+                const double xd = x[d];
+                const double *cd = cs.data() + (size_t)d * nc;
+                for (int k = 0; k < nc; ++k) r[k] += xd * cd[k];
+            }
+            // r = x2 - 2 x.c + c2, the radicand of pair_distances (block_clustering.py:4-5); numpy's argmin over
+            // sqrt(r): a negative r gives NaN and the FIRST NaN wins, otherwise the first minimum
+            int best = 0;
+            double bestv = x2 - 2.0 * r[0] + c2[0];
+            bool best_nan = bestv < 0.0;
+            for (int k = 1; k < nc && !best_nan; ++k) {
+                double v = x2 - 2.0 * r[k] + c2[k];
+                if (v < 0.0) { best = k; best_nan = true; }
+                else if (v < bestv) { best = k; bestv = v; }
+            }
+            block_of[p] = best;
+        }
+    };
+    int nthreads = (int)std::min<long>(8, std::max<long>(1, (long)n * nc / 200000));
+    if (nthreads <= 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        int chunk = (n + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t) {
+            int p0 = t * chunk, p1 = std::min(n, p0 + chunk);
+            if (p0 < p1) th.emplace_back(work, p0, p1);
+        }
+        for (auto &t : th) t.join();
+    }
+    return GPRF_OK;
+}
+
+int gprf_set_block_assignment(gprf_ctx *c, int32_t n_blocks, const int32_t *block_of) {
+    if (!c || n_blocks < 0 || (c->n > 0 && !block_of)) return GPRF_ERR_ARG;
+    std::vector<int64_t> ptr((size_t)n_blocks + 1, 0);
+    for (int p = 0; p < c->n; ++p) {
+        int b = block_of[p];
+        if (b < 0 || b >= n_blocks) return fail(c, GPRF_ERR_ARG, "block id out of range");
+        ptr[b + 1]++;
+    }
+    for (int b = 0; b < n_blocks; ++b) ptr[b + 1] += ptr[b];
+    std::vector<int32_t> pts((size_t)c->n);
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int p = 0; p < c->n; ++p) pts[cur[block_of[p]]++] = p;
+    return gprf_set_blocks(c, n_blocks, ptr.data(), pts.data());
 }
 
 int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {

@@ -53,6 +53,8 @@ class GPRF(object):
         self.X = X
         self.kernelized = False
         self.Y = Y
+        self._block_idxs = None
+        self._block_of = None
         if block_idxs is None:
             block_idxs = block_fn(X)
         self.block_idxs = block_idxs
@@ -90,14 +92,30 @@ class GPRF(object):
     def _push_theta(self):
         self._ctx.set_theta(self._theta())
 
+    @property
+    def block_idxs(self):
+        """list of index arrays (gprf.py:100); built lazily after a library-side re-blocking"""
+        if self._block_idxs is None:
+            order = np.argsort(self._block_of, kind="stable")
+            counts = np.bincount(self._block_of, minlength=self.n_blocks)
+            self._block_idxs = np.split(order, np.cumsum(counts)[:-1])
+        return self._block_idxs
+
+    @block_idxs.setter
+    def block_idxs(self, v):
+        self._block_idxs = v
+        self._block_of = None
+
     def _push_blocks(self):
-        if self._blocks_pushed is self.block_idxs:
+        if self._blocks_pushed == "assignment" and self._block_idxs is None:
+            return
+        if self._blocks_pushed is self._block_idxs:
             return
         ptr, pts = _csr_from_block_idxs(self.block_idxs)
         if len(ptr) - 1 != self.n_blocks:
             raise ValueError("block_fn returned %d blocks, expected %d" % (len(ptr) - 1, self.n_blocks))
         self._ctx.set_blocks(ptr, pts)
-        self._blocks_pushed = self.block_idxs
+        self._blocks_pushed = self._block_idxs
         self._jitter = None
         self._ctx.set_unit_jitter(None)
 
@@ -146,11 +164,27 @@ class GPRF(object):
         self._push_theta()
 
     def update_X(self, new_X, update_blocks=True, recompute_neighbors=False):
-        """gprf.py:169-174: rebinding X re-runs block_fn on every call; the neighbour list stays."""
+        """gprf.py:169-174: rebinding X re-runs block_fn on every call; the neighbour list stays.
+
+        When ``block_fn`` is the ``block_clusters`` method of a grid ``Blocker`` the assignment runs in the C
+        library (gprf_nearest_center + gprf_set_block_assignment) and ``block_idxs`` is materialised only if
+        somebody reads it."""
         self.X = new_X
         if self.block_fn is not None:
-            self.block_idxs = self.block_fn(new_X)
-            self._push_blocks()
+            blocker = getattr(self.block_fn, "__self__", None)
+            from .blocking import Blocker
+            if isinstance(blocker, Blocker) and getattr(self.block_fn, "__name__", "") == "block_clusters" \
+                    and blocker.n_blocks == self.n_blocks:
+                block_of = blocker.block_assignment_fast(new_X)
+                self._ctx.set_block_assignment(self.n_blocks, block_of)
+                self._block_of = block_of
+                self._block_idxs = None
+                self._blocks_pushed = "assignment"
+                self._jitter = None
+                self._ctx.set_unit_jitter(None)
+            else:
+                self.block_idxs = self.block_fn(new_X)
+                self._push_blocks()
         if recompute_neighbors:
             self.compute_neighbors(threshold=self.neighbor_threshold)
             self.compute_neighbor_count()

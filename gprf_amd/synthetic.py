@@ -91,7 +91,7 @@ class SampledData(object):
         b = Blocker(self.centers)
         self.blocker = b
         self.block_idxs = b.block_clusters(self.X_obs)
-        self.reblock = lambda X: b.block_clusters(X)
+        self.reblock = b.block_clusters      # bound method: GPRF.update_X recognises it and re-blocks in C
         self.neighbors = b.neighbors(diag_connections=True)
 
     def build_gprf(self, X=None, cov=None, local_dist=1e-4, **kw):

@@ -68,6 +68,15 @@ int gprf_set_theta(gprf_ctx *ctx, const double *theta, int32_t ntheta);
  * the unit matrices, gprf.py:301,317-326).  Blocks may be empty (gprf.py:507-513). */
 int gprf_set_blocks(gprf_ctx *ctx, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx);
 
+/* Fast host path for the reference's grid Blocker (block_clustering.py:17-26, called from update_X on EVERY
+ * evaluation, gprf.py:171-172): block_of[p] = argmin_c ||x_p - c|| with the reference's
+ * a^2 - 2ab + b^2 radicand and first-minimum tie rule.  Pure host code, no context needed. */
+int gprf_nearest_center(int32_t n, int32_t dx, const double *X, int32_t n_centers, const double *centers,
+                        int32_t *block_of);
+/* Same effect as gprf_set_blocks for the partition block_of[p] in [0, n_blocks): points keep ascending index
+ * order inside each block, exactly like `all_idxs[blocks == i]` (block_clustering.py:21-24). */
+int gprf_set_block_assignment(gprf_ctx *ctx, int32_t n_blocks, const int32_t *block_of);
+
 /* self.neighbors (gprf.py:112,212): n_pairs rows (i, j); each becomes one joint unit with block i's rows
  * first (gprf.py:322).  Bethe weights 1 - deg(i) for the unaries are derived here
  * (compute_neighbor_count gprf.py:152-157; llgrad gprf.py:253-254, 264, 287).  For local=False pass all

@@ -197,6 +197,29 @@ def test_update_X_reblocks_and_update_covs():
     g.close()
 
 
+def test_update_X_fast_reblocking_path_equals_callable_path():
+    """block_fn = Blocker.block_clusters (bound method) is re-blocked inside the C library; a lambda around the
+    same blocker goes through Python.  Same blocks, same numbers; block_idxs is materialised on demand."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(12)
+    X = rng.rand(600, 2)
+    Y = rng.randn(600, 6)
+    b = Blocker(grid_centers(9))
+    cov = GPCov([1.0], [0.2, 0.2], "euclidean", "se")
+    fast = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=b.neighbors())
+    slow = GPRF(X, Y, lambda Z: b.block_clusters(Z), cov, 0.01, neighbors=b.neighbors())
+    X2 = X + 0.04 * rng.randn(600, 2)
+    X2[:3] = b.block_centers[:3]                     # points exactly on centres
+    fast.update_X(X2)
+    slow.update_X(X2)
+    assert fast._blocks_pushed == "assignment" and fast._block_idxs is None
+    a, c = fast.llgrad(grad_X=True, grad_cov=True), slow.llgrad(grad_X=True, grad_cov=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+    assert all(np.array_equal(u, v) for u, v in zip(fast.block_idxs, slow.block_idxs))
+    fast.close(); slow.close()
+
+
 def test_two_shards_on_one_gpu_sum_to_full():
     """The multi-GPU decomposition, exercised on one device: shard (0,2) + shard (1,2) partials add up to
     the unsharded result; device-resident evaluation path (gprf_eval_device)."""

@@ -44,6 +44,19 @@ def test_block_clusters_match_reference_semantics():
         assert np.array_equal(pair_distances(X[:5], X[:7]), H.pair_distances(X[:5], X[:7]), equal_nan=True)
 
 
+def test_fast_nearest_center_equals_numpy_assignment():
+    """gprf_nearest_center (C, host) against the numpy restatement, incl. points exactly on centres (where the
+    reference's radicand goes negative -> NaN -> argmin picks it) and points outside the unit square."""
+    rng = np.random.RandomState(6)
+    for nb in (4, 9, 100, 841):
+        b = Blocker(grid_centers(nb))
+        X = rng.rand(5000, 2) * 1.3 - 0.15
+        X[:4] = b.block_centers[:4]
+        assert np.array_equal(b.block_assignment_fast(X), b.block_assignment(X))
+        assert np.array_equal(b.block_assignment_fast(X), H.BlockerRef(H.grid_centers(nb)).block_clusters and
+                              np.argmin(H.pair_distances(X, b.block_centers), axis=1))
+
+
 def test_csr_packing():
     blocks = [np.array([4, 1]), np.array([], dtype=int), np.array([0, 2, 3])]
     ptr, pts = _csr_from_block_idxs(blocks)
