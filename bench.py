@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak (vendor data sheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): clock under load
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -252,6 +253,7 @@ def main():
         roof["avg_launch_ms"] = stage[dom]
         roof["algorithmic_per_launch"] = fl["fill_bytes"] if dom == "fill" else fl[dom]
         roof["fill_GBps"] = fl["fill_bytes"] / (stage["fill"] * 1e-3) / 1e9
+        roof["mfma_f64_measured_peak"] = FP64_MFMA_MEASURED_TFLOPS
         roof["whole_eval_TFLOPs"] = total_all * value / 1e12
         roof["whole_eval_frac_of_fp64_peak"] = total_all * value / 1e12 / (FP64_PEAK_TFLOPS * world)
         result = {
