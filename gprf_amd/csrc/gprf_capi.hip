@@ -275,12 +275,20 @@ int rebuild_units(gprf_ctx *c) {
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->l_m[a] > c->l_m[b]; });
         int G = std::max(1, std::min(c->n_groups, gprf_ctx::MAX_GROUPS));
-        int pos = 0;
-        for (int g = 0; g < G; ++g) {
-            c->group_begin[g] = pos;
-            for (int k = g; k < nl; k += G) ids[pos++] = order[k];
+        // groups are CONTIGUOUS slices of the descending-size order, so that a group of smaller units leaves
+        // its (latency-bound, step-count-proportional) factorisation early and its later stages overlap the
+        // factorisation tail of the big units; group g gets an equal share of the summed cost
+        for (int k = 0; k < nl; ++k) ids[k] = order[k];
+        double total = 0.0, run = 0.0;
+        auto cost = [&](int l) { double mm = c->l_m[l]; return mm * mm * mm + 4.0 * mm * mm * c->dy; };
+        for (int k = 0; k < nl; ++k) total += cost(order[k]);
+        int g = 0;
+        c->group_begin[0] = 0;
+        for (int k = 0; k < nl; ++k) {
+            run += cost(order[k]);
+            if (g + 1 < G && run >= total * (g + 1) / G) c->group_begin[++g] = k + 1;
         }
-        for (int g = G; g <= gprf_ctx::MAX_GROUPS; ++g) c->group_begin[g] = pos;
+        for (int gg = g + 1; gg <= gprf_ctx::MAX_GROUPS; ++gg) c->group_begin[gg] = nl;
     }
 
     HIP_TRY(c, hipSetDevice(c->device));
