@@ -10,7 +10,7 @@ from . import build as _build
 
 GPRF_OK, GPRF_NOT_PD = 0, 1
 N_STAGES = 7
-STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")
+STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")   # grad = k_mtile + k_gred + k_gx_finalize
 DIST_IDS = {"euclidean": 0, "lld": 1}
 KERN_IDS = {"se": 0, "matern32": 1}
 MAX_UNIT = 512

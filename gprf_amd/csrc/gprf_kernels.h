@@ -72,6 +72,5 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s);
-bool grad_uses_blocks();  // true when launch_grad runs k_grad2 (gcpart indexed by 64-point column block)
 
 }  // namespace gprf

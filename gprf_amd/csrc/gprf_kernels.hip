@@ -13,10 +13,10 @@
 // of k-step q of the next product (rows 4q+lg) — tiles chain through registers.
 //
 // In that form:   K = U^T U            (upper Cholesky, U row-major)              k_potrf
-//                 W = U^-T, Z = U^-T Y (forward substitution on [I | Y])          k_solve
+//                 W = U^-T, Z = U^-T Y (forward substitution on [I | Y])          k_solve_panel (k_solve for m > 288)
 //                 At = Z^T W = (K^-1 Y)^T                                         k_at
-//                 M = At^T At - dy * W^T W  ( = A A^T - dy K^-1 ), reduced on the fly against
-//                 dk/dx and dk/dtheta into gradX rows and gradC partials           k_grad
+//                 M = At^T At - dy * W^T W  ( = A A^T - dy K^-1 ), lower-triangle tiles       k_mtile
+//                 M reduced against dk/dx and dk/dtheta into gradX rows / gradC partials       k_gred
 // Reference identities:  gX[p,i] = sum_q M[p,q] dk(x_p,x_q)/dx_p[i]  (gprf.py:556-573),
 //                        gC[t]   = 1/2 sum_pq M[p,q] dK_pq/dtheta_t  (gprf.py:577-584),
 //                        ll      = -1/2 ||Z||_F^2 - dy sum log U_kk - 1/2 dy m log 2pi (gprf.py:542-544).
@@ -213,51 +213,11 @@ __global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__rest
 // K fill (gprf.py:333-343 -> VectorTree.kernel_matrix + nv I): 64x64 tile per workgroup, lane = column
 // so every wave-store is 512 contiguous bytes.  HBM-write bound: 8 mp^2 bytes per unit.
 // ------------------------------------------------------------------------------------------------
-template <int DIST, int KERN>
-__global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int nt64) {
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
-    int mp = pad16(m);
-    int ti = blockIdx.x / nt64, tj = blockIdx.x % nt64;
-    int r0 = ti * 64, c0 = tj * 64;
-    if (r0 >= mp || c0 >= mp) return;
-    __shared__ double xr[64 * XPAD];
-    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
-    int t = threadIdx.x;
-    {   // 64 rows x 4 coords = 256 values
-        int rr = r0 + (t >> 2);
-        xr[t] = (rr < mp) ? Xu[(size_t)rr * XPAD + (t & 3)] : 0.0;
-    }
-    int col = c0 + (t & 63);
-    double xj[XPAD];
-    for (int d = 0; d < XPAD; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XPAD + d] : 0.0;
-    __syncthreads();
-    if (col >= mp) return;
-    double *U = pl.U + ut.mat_off[u];
-    double diag_add = kp.nv + ut.jitter[u];
-    int rbase = t >> 6;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        int rl = rbase + 4 * q;
-        int row = r0 + rl;
-        if (row >= mp) break;
-        double v;
-        if (row < m && col < m) {
-            v = KernFn<DIST, KERN>::value(kp, &xr[rl * XPAD], xj);
-            if (row == col) v += diag_add;
-        } else {
-            v = (row == col) ? 1.0 : 0.0;
-        }
-        U[(size_t)row * mp + col] = v;
-    }
-}
-
-
-// k_fill2: the same fill by symmetry — one workgroup per 64x64 tile pair (ti <= tj): evaluates the tile once
+// k_fill: the same fill by symmetry — one workgroup per 64x64 tile pair (ti <= tj): evaluates the tile once
 // (lane = column: 512-B wave stores), mirrors it through LDS and writes the transposed tile with the same
 // coalescing.  Halves the exp() work; the bytes written stay 8 mp^2 per unit.
 template <int DIST, int KERN>
-__global__ __launch_bounds__(256) void k_fill2(UnitTab ut, Pools pl, KParams kp) {
+__global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) {
     __shared__ double xr[64 * XPAD];
     __shared__ double tb[64 * 65];
     int u = ut.ids[blockIdx.y];
@@ -323,135 +283,8 @@ __global__ __launch_bounds__(256) void k_fill2(UnitTab ut, Pools pl, KParams kp)
 // ------------------------------------------------------------------------------------------------
 constexpr int POTRF_WAVES = 8;
 
-__global__ __launch_bounds__(POTRF_WAVES * 64) void k_potrf(UnitTab ut, Pools pl) {
-    extern __shared__ double lds[];
-    __shared__ int s_fail;
-    int u = ut.ids[blockIdx.x];
-    int m = ut.m[u];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    if (m == 0) {
-        if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
-        return;
-    }
-    int mp = pad16(m), T = mp >> 4;
-    int ldp = mp + ((T & 1) ? 0 : 16);  // (ldp/16) odd: lane groups lg, lg+1 land 32 banks apart
-    double *P = lds;                    // [16][ldp] current row panel of U
-    double *Vd = lds + 16 * ldp;        // [16][16]  V_jj
-    double *U = pl.U + ut.mat_off[u];
-    double *V = pl.V + (size_t)ut.row_off[u] * 16;
-    if (threadIdx.x == 0) s_fail = 0;
-    double logsum = 0.0;
-    __syncthreads();
-
-    for (int j = 0; j < T; ++j) {
-        // ---- (a) diagonal tile: unblocked upper Cholesky + inverse, wave 0, column lr per lane ----
-        if (wave == 0) {
-            double s[16], v[16];
-            const double *Cjj = U + (size_t)(16 * j) * mp + 16 * j;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = Cjj[(size_t)i * mp + lr];
-            int bad = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double pkk = readlane_d(s[k], k);
-                if (!(pkk > 0.0)) {
-                    if (!bad) bad = 16 * j + k + 1;
-                    pkk = 1.0;
-                }
-                double d = sqrt(pkk);
-                logsum += log(d);
-                double ukc = (lr > k) ? s[k] / d : ((lr == k) ? d : 0.0);
-                s[k] = ukc;
-#pragma unroll
-                for (int i = k + 1; i < 16; ++i) {
-                    double uki = readlane_d(ukc, i);
-                    s[i] -= uki * ukc;
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the readlane->SGPR live ranges per step
-            }
-            // V = U_jj^-1 (upper): back substitution, column lr per lane
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = 0.0;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {
-                double acc = (i == lr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = i + 1; k < 16; ++k) {
-                    double uik = readlane_d(s[i], k);
-                    acc -= uik * v[k];
-                }
-                double uii = readlane_d(s[i], i);
-                v[i] = (i <= lr) ? acc / uii : 0.0;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (lane < 16) {
-                double *Ujj = U + (size_t)(16 * j) * mp + 16 * j;
-                double *Vj = V + (size_t)j * 256;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    double uv = (i <= lr) ? s[i] : 0.0;
-                    Ujj[(size_t)i * mp + lr] = uv;
-                    Vd[i * 16 + lr] = v[i];
-                    Vj[i * 16 + lr] = v[i];
-                }
-                if (bad && lane == 0) s_fail = bad;
-            }
-        }
-        __syncthreads();
-        if (s_fail) {
-            if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
-            return;
-        }
-        // ---- (b) row panel: U_jk = V_jj^T C_jk, k > j ----
-        for (int k = j + 1 + wave; k < T; k += POTRF_WAVES) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const double *Cjk = U + (size_t)(16 * j) * mp + 16 * k;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double a = Vd[(4 * s + lg) * 16 + lr];
-                double b = Cjk[(size_t)(4 * s + lg) * mp + lr];
-                acc = mfma(a, b, acc);
-            }
-            double *Ujk = U + (size_t)(16 * j) * mp + 16 * k;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                Ujk[(size_t)(lg + 4 * q) * mp + lr] = acc[q];
-                P[(lg + 4 * q) * ldp + 16 * k + lr] = acc[q];
-            }
-        }
-        __syncthreads();
-        // ---- (c) trailing update: C_ik -= U_ji^T U_jk, j < i <= k < T ----
-        int ntr = T - j - 1;
-        int ntile = ntr * (ntr + 1) / 2;
-        for (int t = wave; t < ntile; t += POTRF_WAVES) {
-            int a_ = 0, rem = t;
-            while (rem >= ntr - a_) { rem -= ntr - a_; ++a_; }
-            int i = j + 1 + a_, k = i + rem;
-            double *Cik = U + (size_t)(16 * i) * mp + 16 * k;
-            d4 acc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = Cik[(size_t)(lg + 4 * q) * mp + lr];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double a = -P[(4 * s + lg) * ldp + 16 * i + lr];
-                double b = P[(4 * s + lg) * ldp + 16 * k + lr];
-                acc = mfma(a, b, acc);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Cik[(size_t)(lg + 4 * q) * mp + lr] = acc[q];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        pl.logdet[u] = 2.0 * logsum;  // log|K| = 2 sum log U_kk
-        pl.info[u] = 0;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// k_potrf2: the same blocked upper Cholesky, re-scheduled around its critical path
+// k_potrf: the same blocked upper Cholesky, re-scheduled around its critical path
 //     diag(j) -> row panel(j) -> update of tile (j+1,j+1) -> diag(j+1) -> ...
 // * look-ahead: once row panel j is in LDS, wave 0 alone updates tile (j+1,j+1) and factors it while
 //   waves 1..7 apply the rest of the trailing update (MFMA, both operands from the LDS panel);
@@ -509,7 +342,7 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk
     return bad;
 }
 
-__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pools pl, int ablate) {
+__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools pl, int stamps) {
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
@@ -557,9 +390,9 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     }
     __syncthreads();
 
-    // diagnostic stamps (ablate & 16): cycles wave 0 spends in [row panel | barrier | factor | barrier]
+    // diagnostic stamps (GPRF_POTRF_STAMPS=1): cycles wave 0 spends in [row panel | barrier | factor | barrier]
     unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
-    bool stamp = (ablate & 16) && threadIdx.x == 0;
+    bool stamp = stamps && threadIdx.x == 0;
 #define GPRF_STAMP(k)                                                     \
     if (stamp) {                                                          \
         unsigned long long tn = __builtin_amdgcn_s_memtime();             \
@@ -578,7 +411,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
         int ncol = 16 * ntr;
         for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
             int col = 16 * (j + 1) + c0 + lane;
-            if (c0 + lane < ncol && !(ablate & 1)) {
+            if (c0 + lane < ncol) {
                 double x[16];
                 double *Cc = U + (size_t)(16 * j) * mp + col;
 #pragma unroll
@@ -599,9 +432,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
         GPRF_STAMP(0)
         __syncthreads();
         GPRF_STAMP(1)
-        if (wave == 0 && (ablate & 2)) {
-            if (lane < 16) { rdt[lr] = 1.0; dvals[16 * (j + 1) + lr] = 1.0; }
-        } else if (wave == 0) {
+        if (wave == 0) {
             // look-ahead: tile (j+1, j+1) -> LDS (row-major) -> one column per lane -> factor
             int i = j + 1;
             const double *Cii = U + (size_t)(16 * i + lg) * mp + 16 * i + lr;
@@ -625,7 +456,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
             // trailing update without tile (j+1,j+1): tile rows i = j+1 .. T-1 dealt cyclically to waves 1..7; along
             // a row the A operand (column block i of the panel) is read once, the pointer just advances by one
             // tile, and the next tile's C values are in flight while the current tile's MFMAs run
-            if (!(ablate & 4)) {
+            {
                 for (int i = j + 1 + (wave - 1); i < T; i += POTRF_WAVES - 1) {
                     double a[4];
 #pragma unroll
@@ -669,7 +500,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     }
     // ---- V_jj = U_jj^-1 for every diagonal tile: 4 tiles per wave at a time, lane (lg, lr) = row lr of
     //      tile 4*grp + lg;  apply to I the column operations that reduce U_jj to I ----
-    for (int grp = wave; 4 * grp < T && !(ablate & 8); grp += POTRF_WAVES) {
+    for (int grp = wave; 4 * grp < T; grp += POTRF_WAVES) {
         int jt = 4 * grp + lg;
         double *Us = P + jt * 256;            // the panel buffer is free now: 256 T <= 16 ldp doubles
         if (jt < T) {
@@ -700,246 +531,6 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf2(UnitTab ut, Pool
     if (lane == 0) lred[wave] = part;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < POTRF_WAVES; ++w) t += lred[w];
-        pl.logdet[u] = 2.0 * t;
-        pl.info[u] = 0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_potrf3: blocked upper Cholesky with the TRAILING MATRIX RESIDENT IN REGISTERS.
-// With every unit of an evaluation in flight at once, a trailing matrix that lives in global memory is
-// re-read and re-written from beyond the L2 at every panel step (measured: 150 of k_potrf2's 183 us at
-// n=10000/442 units is that traffic).  Here the T(T+1)/2 upper-triangle tiles are dealt round-robin to waves
-// 1..7 as MFMA accumulators (<= SLOTS tiles = 8*SLOTS VGPRs per wave) and stay there for the whole
-// factorisation; K is read once, U is written once.  Per panel step j:
-//   S1  owners drop their row-j tiles (j,k) into the LDS panel            | barrier
-//   S2  all 8 waves: forward substitution U_jk = U_jj^-T C_jk in place in LDS (one column per lane, U_jj
-//       broadcast from LDS), final rows also written to global           | barrier
-//   S3  the owner of tile (j+1,j+1) updates it first and hands it over through LDS | barrier
-//   S4  wave 0 factors that tile (look-ahead) while waves 1..7 update the rest of their tiles from the panel
-// ------------------------------------------------------------------------------------------------
-template <int SLOTS>
-__global__ __launch_bounds__(POTRF_WAVES * 64, 2) void k_potrf3(UnitTab ut, Pools pl, int ablate) {
-    extern __shared__ double lds[];
-    __shared__ int s_fail;
-    __shared__ double lred[POTRF_WAVES];
-    constexpr int NW = POTRF_WAVES - 1;   // worker waves
-    int u = ut.ids[blockIdx.x];
-    int m = ut.m[u];
-    int tid = threadIdx.x;
-    int lane = tid & 63, wave = tid >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    if (m == 0) {
-        if (tid == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
-        return;
-    }
-    int mp = pad16(m), T = mp >> 4;
-    int NT = T * (T + 1) / 2;
-    int ldp = mp + ((T & 1) ? 0 : 16);
-    double *P = lds;                      // [16][ldp] row panel j (raw, then solved in place)
-    double *Ud = P + 16 * ldp;            // [16][16]  U_jj
-    double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
-    double *Tt = rdt + 16;                // [16][17]  hand-over tile, row-major
-    double *dvals = Tt + 16 * 17;         // [mp]      diagonal of U
-    int *tik = (int *)(dvals + mp);       // [NT]      (i << 8) | k of tile t
-    double *U = pl.U + ut.mat_off[u];
-    double *V = pl.V + (size_t)ut.row_off[u] * 16;
-    if (tid == 0) s_fail = 0;
-    for (int t = tid; t < NT; t += POTRF_WAVES * 64) {
-        int a_ = 0, rem = t;
-        while (rem >= T - a_) { rem -= T - a_; ++a_; }
-        tik[t] = (a_ << 8) | (a_ + rem);
-    }
-    __syncthreads();
-
-    auto publish = [&](double (&s)[16], double dk, double rdk, int jt, int bad) {
-        if (lane < 16) {
-            double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double uv = (i <= lr) ? s[i] : 0.0;
-                Ujj[(size_t)i * mp + lr] = uv;
-                Ud[i * 16 + lr] = uv;
-            }
-            rdt[lr] = rdk;
-            dvals[16 * jt + lr] = dk;
-            if (bad && lane == 0) s_fail = 16 * jt + bad;
-        }
-    };
-    // S2, shared by both roles: forward substitution in place on the LDS panel, one column per lane
-    auto trsm_panel = [&](int j) {
-        int ncol = 16 * (T - j - 1);
-        for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
-            int col = 16 * (j + 1) + c0 + lane;
-            if (c0 + lane < ncol) {
-                double x[16];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) x[a] = P[a * ldp + col];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    x[c] *= rdt[c];
-#pragma unroll
-                    for (int a = c + 1; a < 16; ++a) x[a] -= Ud[c * 16 + a] * x[c];
-                }
-                double *Cc = U + (size_t)(16 * j) * mp + col;
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    Cc[(size_t)a * mp] = x[a];
-                    P[a * ldp + col] = x[a];
-                }
-            }
-        }
-    };
-    // The two roles run DIFFERENT code with the SAME barrier sequence (4 per step), so the factor wave's
-    // registers and the workers' accumulators never have to coexist in one allocation.
-    bool failed = false;
-    if (wave == 0) {
-        {
-            double s[16], dk, rdk;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = U[(size_t)i * mp + lr];
-            int bad = diag_factor16(s, lr, &dk, &rdk);
-            publish(s, dk, rdk, 0, bad);
-        }
-        unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
-        bool stamp = (ablate & 16) && tid == 0;
-#define GPRF_STAMP(k)                                                     \
-        if (stamp) {                                                      \
-            unsigned long long tn = __builtin_amdgcn_s_memtime();         \
-            tacc[k] += tn - tprev;                                        \
-            tprev = tn;                                                   \
-        }
-        if (stamp) tprev = __builtin_amdgcn_s_memtime();
-        for (int j = 0; j < T; ++j) {
-            lds_barrier();                                     // B1 (after S1)
-            GPRF_STAMP(0)
-            if (s_fail) { failed = true; break; }
-            if (T - j - 1 == 0) break;
-            trsm_panel(j);                                     // S2
-            GPRF_STAMP(1)
-            lds_barrier();                                     // B2
-            lds_barrier();                                     // B3 (after S3: tile (j+1,j+1) is in Tt)
-            GPRF_STAMP(2)
-            double s[16], dk, rdk;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = Tt[r * 17 + lr];
-            int bad = diag_factor16(s, lr, &dk, &rdk);
-            publish(s, dk, rdk, j + 1, bad);                   // S4 (look-ahead factor)
-            GPRF_STAMP(3)
-            lds_barrier();                                     // B4
-            GPRF_STAMP(4)
-        }
-        if (stamp) {
-            for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
-            pl.dbg[(size_t)u * 8 + 5] = (double)T;
-        }
-#undef GPRF_STAMP
-    } else {
-        d4 acc[SLOTS];
-        int ik[SLOTS];
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) {
-            int t = (wave - 1) + NW * sl;
-            bool have = t < NT;
-            int v = have ? tik[t] : 0xffff;                    // i = 255: never matches a row
-            v = __builtin_amdgcn_readfirstlane(v);
-            ik[sl] = v;
-            acc[sl] = d4{0.0, 0.0, 0.0, 0.0};
-            if (have) {
-                int i = v >> 8, k = v & 255;
-                const double *C = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[sl][q] = C[(size_t)(4 * q) * mp];
-            }
-        }
-        for (int j = 0; j < T; ++j) {
-            // per-iteration opaque copy of the lane's column: keeps the 22 x 8 LDS tile addresses from being
-            // hoisted out of the loop (they would occupy as many registers as the accumulators)
-            int lrv = lr, lgv = lg;
-            asm volatile("" : "+v"(lrv), "+v"(lgv));
-            // ---- S1: row-j tiles -> LDS panel ----
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                int i = ik[sl] >> 8, k = ik[sl] & 255;
-                if (i == j && k > j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) P[(lgv + 4 * q) * ldp + 16 * k + lrv] = acc[sl][q];
-                }
-            }
-            lds_barrier();                                     // B1
-            if (s_fail) { failed = true; break; }
-            if (T - j - 1 == 0) break;
-            trsm_panel(j);                                     // S2
-            lds_barrier();                                     // B2
-            // ---- S3: the owner of (j+1, j+1) updates it first and hands it over ----
-            int jn = j + 1;
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                if (ik[sl] == ((jn << 8) | jn)) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        double a = P[(4 * s + lgv) * ldp + 16 * jn + lrv];
-                        acc[sl] = mfma(-a, a, acc[sl]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Tt[(lgv + 4 * q) * 17 + lrv] = acc[sl][q];
-                }
-            }
-            lds_barrier();                                     // B3
-            // ---- S4: trailing update of everything else this wave owns ----
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                int i = ik[sl] >> 8, k = ik[sl] & 255;
-                if (i > j && i < 255 && !(i == jn && k == jn)) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        double a = -P[(4 * s + lgv) * ldp + 16 * i + lrv];
-                        double b = P[(4 * s + lgv) * ldp + 16 * k + lrv];
-                        acc[sl] = mfma(a, b, acc[sl]);
-                    }
-                }
-            }
-            lds_barrier();                                     // B4: P, Ud, rdt are free for the next step
-        }
-    }
-    if (failed || s_fail) {
-        if (tid == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
-        return;
-    }
-    // ---- V_jj = U_jj^-1 for every diagonal tile (4 tiles per wave at a time) ----
-    __syncthreads();
-    for (int grp = wave; 4 * grp < T; grp += POTRF_WAVES) {
-        int jt = 4 * grp + lg;
-        double *Us = P + jt * 256;
-        if (jt < T) {
-            const double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Us[i * 16 + lr] = Ujj[(size_t)i * mp + lr];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (jt < T) {
-            double v[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = (c == lr) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                v[k] *= 1.0 / Us[k * 16 + k];
-#pragma unroll
-                for (int i = k + 1; i < 16; ++i) v[i] -= Us[k * 16 + i] * v[k];
-            }
-            double *Vj = V + (size_t)jt * 256 + lr * 16;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Vj[c] = v[c];
-        }
-    }
-    double part = 0.0;
-    for (int r = tid; r < mp; r += POTRF_WAVES * 64) part += log(dvals[r]);
-    for (int off = 32; off >= 1; off >>= 1) part += shfl_xor_d(part, off);
-    if (lane == 0) lred[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < POTRF_WAVES; ++w) t += lred[w];
         pl.logdet[u] = 2.0 * t;
@@ -1053,135 +644,15 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Forward substitution, register-resident form (units with T <= SOLVE2_MAXT): ONE WAVE per 16-column block
-// of [I | Yu].  The block's tiles for all rows stay in MFMA accumulators; the freshly solved tile w_r is
-// already in B-operand layout (accumulator register q = rows 4q+lg), so the right-looking updates
-// acc_r' -= U_{r,r'}^T w_r chain through registers with no LDS and no barrier.  Only U tiles (shared by
-// the 4 waves of the workgroup through L1) and the 16x16 diagonal inverses are read from memory.
-// ------------------------------------------------------------------------------------------------
-constexpr int SOLVE2_MAXT = 18;  // largest instantiation: 18 tiles x 8 VGPRs of accumulators, 2 waves/SIMD
+constexpr int SOLVE_PANEL_MAXT = 18;  // largest k_solve_panel instantiation (accumulators: 18 tiles x 8 VGPRs)
 
-template <int SOLVE2_MAXT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_solve2(UnitTab ut, Pools pl) {
-    int slot_, part_;
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 4 + 3) >> 2, &slot_, &part_)) return;
-    int u = ut.ids[slot_];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    int cbx = part_ * 4 + wave;
-    bool is_y = cbx >= ut.max_T;
-    int cb = is_y ? (cbx - ut.max_T) : cbx;
-    if (is_y ? (cb >= 4) : (cb >= T)) return;
-    size_t roff = ut.row_off[u];
-    if (T == 0) {
-        if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
-        return;
-    }
-    const double *__restrict__ U = pl.U + ut.mat_off[u];
-    const double *__restrict__ V = pl.V + roff * 16;
-    double *__restrict__ W = pl.W + ut.mat_off[u];
-    double *__restrict__ Z = pl.Z + roff * YPAD;
-    const double *__restrict__ Yu = pl.Yu + roff * YPAD;
-    int r0 = is_y ? 0 : cb;
-
-    // accumulator slot r = row tile r (slots above r0 stay unused): every wave of the workgroup walks the rows
-    // r = 0, 1, ... in the same order, so their reads of the U tiles of row r coincide in L1
-    d4 acc[SOLVE2_MAXT];
-#pragma unroll
-    for (int r = 0; r < SOLVE2_MAXT; ++r) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double v = 0.0;
-            if (r >= r0 && r < T) {
-                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
-                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
-            }
-            acc[r][q] = v;
-        }
-    }
-    double zz = 0.0;
-#pragma unroll
-    for (int r = 0; r < SOLVE2_MAXT; ++r) {
-        if (r >= r0 && r < T) {
-            const double *Vr = V + (size_t)r * 256 + lg * 16 + lr;
-            d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) w = mfma(Vr[64 * s], acc[r][s], w);
-            if (is_y) {
-                double *zp = Z + (size_t)(16 * r + lg) * YPAD + 16 * cb + lr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    zp[(size_t)(4 * q) * YPAD] = w[q];
-                    zz += w[q] * w[q];
-                }
-            } else {
-                double *wp = W + (size_t)(16 * r + lg) * mp + 16 * cb + lr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) wp[(size_t)(4 * q) * mp] = w[q];
-            }
-            // rows below: acc_{r2} -= U_{r,r2}^T w   (tile (r, r2) of U, r2 > r)
-            const double *Ur = U + (size_t)(16 * r + lg) * mp + lr;
-            const double *u0 = Ur, *u1 = Ur + (size_t)4 * mp, *u2 = Ur + (size_t)8 * mp, *u3 = Ur + (size_t)12 * mp;
-#pragma unroll
-            for (int r2 = r + 1; r2 < SOLVE2_MAXT; ++r2) {
-                if (r2 < T) {
-                    acc[r2] = mfma(-u0[16 * r2], w[0], acc[r2]);
-                    acc[r2] = mfma(-u1[16 * r2], w[1], acc[r2]);
-                    acc[r2] = mfma(-u2[16 * r2], w[2], acc[r2]);
-                    acc[r2] = mfma(-u3[16 * r2], w[3], acc[r2]);
-                }
-            }
-        }
-    }
-    if (is_y) {
-        for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
-        if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = zz;
-    }
-}
-
-// At = Z^T W, one wave per column tile I of the unit computing all four 16-row blocks of At (the W tile is
-// the shared B operand: 5 loads per 4 MFMAs).
-__global__ __launch_bounds__(256) void k_at2(UnitTab ut, Pools pl) {
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int I = blockIdx.x * 4 + wave;
-    if (I >= T) return;
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ W = pl.W + ut.mat_off[u];
-    const double *__restrict__ Z = pl.Z + roff * YPAD;
-    double *__restrict__ At = pl.At + roff * YPAD;
-    d4 acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int kt = I; kt < T; ++kt) {
-        const double *wp = W + (size_t)(16 * kt + lg) * mp + 16 * I + lr;
-        const double *zp = Z + (size_t)(16 * kt + lg) * YPAD + lr;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double b = wp[(size_t)(4 * s) * mp];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma(zp[(size_t)(4 * s) * YPAD + 16 * c], b, acc[c]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[c][q];
-}
-
-
-// k_solve4: the same forward substitution with the U row panel of each step staged ONCE per workgroup in LDS
+// k_solve_panel: the same forward substitution with the U row panel of each step staged ONCE per workgroup in LDS
 // (cooperative, coalesced loads of panel r+1 overlap step r's MFMAs; one barrier per step), so the four waves
 // — four RHS column blocks — share every U tile and each update MFMA costs one conflict-free ds_read.
-// Accumulators stay in registers as in k_solve2.
+// Each wave's tiles for all rows stay in MFMA accumulators; the freshly solved tile is already in B-operand layout
+// (accumulator register q = rows 4q+lg), so the right-looking updates chain through registers.
 template <int MAXT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_solve4(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) {
     constexpr int LDP = 16 * MAXT + 16;          // (LDP/16) odd: lane groups 32 banks apart
     constexpr int NCH = (16 * MAXT + 63) / 64;
     __shared__ double panel[2][16 * LDP];
@@ -1290,11 +761,11 @@ __global__ __launch_bounds__(256, WPS) void k_solve4(UnitTab ut, Pools pl) {
     }
 }
 
-// k_at3: At = Z^T W with one workgroup per 16 column tiles of the unit; wave w owns the column tiles
+// k_at: At = Z^T W with one workgroup per 16 column tiles of the unit; wave w owns the column tiles
 // I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
-__global__ __launch_bounds__(256, 2) void k_at3(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     int slot_, part_;
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
     int u = ut.ids[slot_];
@@ -1350,157 +821,10 @@ __global__ __launch_bounds__(256, 2) void k_at3(UnitTab ut, Pools pl) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// At = Z^T W  = (K^-1 Yu)^T  (the second triangular solve of dpotrs, gpy_linalg.py:139-148, as a product
-// with the explicit W).  Workgroup per column tile I of the unit, wave = 16-row block of At (Y columns).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_at(UnitTab ut, Pools pl) {
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int I = blockIdx.x;
-    if (I >= T) return;
-    int lane = threadIdx.x & 63, cbk = threadIdx.x >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *W = pl.W + ut.mat_off[u];
-    const double *Z = pl.Z + roff * YPAD;
-    double *At = pl.At + roff * YPAD;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kt = I; kt < T; ++kt) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            size_t krow = (size_t)(16 * kt + 4 * s + lg);
-            double a = Z[krow * YPAD + 16 * cbk + lr];
-            double b = W[krow * mp + 16 * I + lr];
-            acc = mfma(a, b, acc);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) At[(size_t)(16 * cbk + lg + 4 * q) * mp + 16 * I + lr] = acc[q];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Gradient reduce.  Workgroup per (unit, column tile J); waves stride over row tiles I.  For each tile
-//   M_IJ = At_I^T At_J - dy * sum_{k >= max(I,J)} W_kI^T W_kJ          (MFMA, never stored)
-// and, by symmetry of M and k, the column sums give the rows of gradX for the 16 points of tile J:
-//   gX[j][d] = sum_i M[i][j] * dk(x_j, x_i)/dx_j[d]                       (gprf.py:556-573)
-//   gC partials: tr(M), sum M*k_noise_free, sum M*dk/dl_t                 (gprf.py:577-584, 362-375)
-// ------------------------------------------------------------------------------------------------
-template <int DIST, int KERN>
-__global__ __launch_bounds__(256) void k_grad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
-    __shared__ double red[4][16][8];
-    __shared__ double gcred[4][8];
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int J = blockIdx.x;
-    if (J >= T) return;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *W = pl.W + ut.mat_off[u];
-    const double *At = pl.At + roff * YPAD;
-    const double *Xu = pl.Xu + roff * XPAD;
-    int j = 16 * J + lr;
-    double xj[XPAD];
-#pragma unroll
-    for (int d = 0; d < XPAD; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
-    int nks = (kp.dy + 3) >> 2;  // k-steps over the Y columns (rows of At); pad rows are zero
-    double dyd = (double)kp.dy;
-
-    double gx[3] = {0.0, 0.0, 0.0};
-    double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
-
-    for (int I = wave; I < T; I += 4) {
-        d4 accA = {0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < nks; ++s) {
-            size_t krow = (size_t)(4 * s + lg);
-            double a = At[krow * mp + 16 * I + lr];
-            double b = At[krow * mp + 16 * J + lr];
-            accA = mfma(a, b, accA);
-        }
-        d4 accP = {0.0, 0.0, 0.0, 0.0};
-        int k0 = (I > J) ? I : J;
-        for (int kt = k0; kt < T; ++kt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                size_t krow = (size_t)(16 * kt + 4 * s + lg);
-                double a = W[krow * mp + 16 * I + lr];
-                double b = W[krow * mp + 16 * J + lr];
-                accP = mfma(a, b, accP);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int i = 16 * I + lg + 4 * q;
-            if (i < m && j < m) {
-                double Mij = accA[q] - dyd * accP[q];
-                double xi[XPAD];
-#pragma unroll
-                for (int d = 0; d < XPAD; ++d) xi[d] = Xu[(size_t)i * XPAD + d];
-                double dkdx[3] = {0.0, 0.0, 0.0}, dkdl[3] = {0.0, 0.0, 0.0};
-                double k = KernFn<DIST, KERN>::full(kp, xi, xj, dkdx, dkdl);
-                if (i != j) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) gx[d] += Mij * dkdx[d];
-                } else {
-                    gc_tr += Mij;
-                }
-                if (want_gc) {
-                    gc_sv += Mij * k;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
-                }
-            }
-        }
-    }
-    // column sums: over the 4 lane groups (rows lg + 4q), then over the 4 waves (row tiles)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        gx[d] += shfl_xor_d(gx[d], 16);
-        gx[d] += shfl_xor_d(gx[d], 32);
-    }
-    if (lg == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) red[wave][lr][d] = gx[d];
-    }
-    double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int jj = threadIdx.x >> 2, d = threadIdx.x & 3;
-        double v = 0.0;
-        if (d < 3) v = red[0][jj][d] + red[1][jj][d] + red[2][jj][d] + red[3][jj][d];
-        pl.gXu[(roff + 16 * J + jj) * XPAD + d] = v;
-    }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + GC_SLOTS) {
-        int t = threadIdx.x - 64;
-        double v = 0.0;
-        if (t < 5) v = gcred[0][t] + gcred[1][t] + gcred[2][t] + gcred[3][t];
-        pl.gcpart[((size_t)u * ut.max_T + J) * GC_SLOTS + t] = v;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// k_grad2: the same reduction on the LOWER triangle of M only, with LDS-staged operands.
-// Workgroup = (unit, 64-column block JB); it walks the 64-row blocks IB >= JB.  For a block pair the K-loop
-// runs over 16-row chunks of the stacked operand [At ; W] (both row-major with leading dimension mp):
-// a chunk's 64 I-columns and 64 J-columns are staged once in LDS (double buffered, one barrier per chunk)
-// and feed all 16 tile products of the block: wave w owns row tile I = 4 IB + w against the four J tiles
-// (1 A read + 4 B reads per 4 MFMAs; W chunks first, the accumulators are then scaled by -dy and the At
-// chunks continue in the same registers).  M = At^T At - dy W^T W is symmetric and so is k, hence a strictly
-// lower tile (I > J) contributes its column sums to gradX of the J points AND its row sums to gradX of the I
-// points (and twice to the hyper-parameter sums); its k values are read back from the strictly-lower part of
-// the K/U pool, which the Cholesky never touches — only diagonal tiles re-evaluate exp().
-// Row sums leave through rowpart[row][JB] and are folded into gXu by k_gx_finalize (fixed order).
+// Gradient reduce: M = At^T At - dy W^T W (= A A^T - dy K^-1) on the lower triangle, reduced against dk/dx and
+// dk/dtheta.  By symmetry of M and k a strictly-lower tile (I > J) gives column sums to the points of J and row sums
+// to the points of I:  gX[j][d] = sum_i M[i][j] dk(x_j, x_i)/dx_j[d]  (gprf.py:556-573);
+// gC partials: tr(M), sum M*k_noise_free, sum M*dk/dl_t (gprf.py:577-584, 362-375).
 // ------------------------------------------------------------------------------------------------
 constexpr int G2_LD = 144;   // staged chunk row stride in doubles: 128 columns + 16 (lane groups 32 banks apart)
 
@@ -1517,245 +841,15 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
-template <int DIST, int KERN>
-__global__ __launch_bounds__(256, 2) void k_grad2(UnitTab ut, Pools pl, KParams kp, int want_gc, int ablate) {
-    __shared__ double chunk[2][16 * G2_LD];
-    __shared__ double red[4][64][4];
-    __shared__ double gcred[4][8];
-    int slot, JB;
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 3) >> 2, &slot, &JB)) return;
-    int u = ut.ids[slot];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int TB = (T + 3) >> 2;
-    if (JB >= TB) return;
-    int tid = threadIdx.x;
-    int lane = tid & 63, wave = tid >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ W = pl.W + ut.mat_off[u];
-    const double *__restrict__ Kp = pl.U + ut.mat_off[u];     // strictly-lower tiles still hold K
-    const double *__restrict__ At = pl.At + roff * YPAD;
-    const double *__restrict__ Xu = pl.Xu + roff * XPAD;
-    int J0 = 4 * JB;
-    double dyd = (double)kp.dy;
-    int nchA = (kp.dy + 15) >> 4;                      // At chunks (16 rows each; rows >= dy are zero)
-
-    // column sums of M_ij * (dk/dx_j) [SE: of g*delta_d, scaled at the end], hyper-parameter sums
-    double colsum[4][3];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) colsum[jj][d] = 0.0;
-    double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
-
-    // staging: element e of this thread = chunk row 2e + (tid >> 7), column tid & 127 (0..63 I, 64..127 J):
-    // every wave-load is 512 contiguous bytes
-    int s_col = tid & 127, s_row0 = tid >> 7;
-    bool s_isJ = s_col >= 64;
-
-    for (int IB = JB; IB < TB; ++IB) {
-        int I = 4 * IB + wave;
-        bool active = I < T;
-        int scol = s_isJ ? (64 * JB + (s_col - 64)) : (64 * IB + s_col);
-        bool scol_ok = scol < mp;
-        int nchW = T - 4 * IB;                 // W chunks kt = 4 IB .. T-1 come FIRST, then the At chunks
-        int nch = nchW + nchA;
-        d4 acc[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[jj] = d4{0, 0, 0, 0};
-        bool need[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) need[jj] = active && (J0 + jj <= I) && (J0 + jj < T);
-
-        // two register sets: chunk c+1 and c+2 are in flight while chunk c is multiplied
-        double pre0[8], pre1[8];
-        auto src_of = [&](int c) -> const double * {
-            return (c < nchW) ? (W + (size_t)(16 * (4 * IB + c) + s_row0) * mp + scol)
-                              : (At + (size_t)(16 * (c - nchW) + s_row0) * mp + scol);
-        };
-        auto fetch0 = [&](int c) {
-            const double *src = src_of(c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pre0[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
-        };
-        auto fetch1 = [&](int c) {
-            const double *src = src_of(c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
-        };
-        // one staged chunk -> 16 tile products of this wave
-        auto mma_chunk = [&](const double *buf) {
-            const double *rowp = buf + lg * G2_LD + lr;
-            double a[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = rowp[(4 * s) * G2_LD + 16 * wave];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (need[jj]) {
-                    double b[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b[s] = rowp[(4 * s) * G2_LD + 64 + 16 * jj];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[jj] = mfma(a[s], b[s], acc[jj]);
-                }
-            }
-        };
-        auto step = [&](int c, double (&pre)[8], bool refill_even) {
-            double *buf = chunk[c & 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
-            __syncthreads();
-            if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
-            if (!(ablate & 1)) {
-                if (c < nchW) {
-                    if (active && (4 * IB + c) >= I) mma_chunk(buf);
-                } else {
-                    if (c == nchW) {
-                        // acc held sum W^T W = (K^-1)_IJ so far: M = -dy K^-1 + A A^T continues in the same registers
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[jj][q] *= -dyd;
-                    }
-                    if (active) mma_chunk(buf);
-                }
-            }
-        };
-        fetch0(0);
-        if (nch > 1) fetch1(1);
-        for (int c = 0; c < nch; c += 2) {
-            step(c, pre0, true);
-            if (c + 1 < nch) step(c + 1, pre1, false);
-        }
-        __syncthreads();   // the next block's first staging write reuses chunk[0]
-        // ---- epilogue of block (IB, JB) for this wave's row tile ----
-        if (active && !(ablate & 2)) {
-            double rowsum[4][3];
-            double xi[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int i = 16 * I + lg + 4 * q;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    rowsum[q][d] = 0.0;
-                    xi[q][d] = Xu[(size_t)i * XPAD + d];
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (!need[jj]) continue;
-                int J = J0 + jj;
-                bool offdiag = I > J;
-                int j = 16 * J + lr;
-                double wgt = offdiag ? 2.0 : 1.0;
-                double xjv[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) xjv[d] = Xu[(size_t)j * XPAD + d];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int i = 16 * I + lg + 4 * q;
-                    bool ok = (i < m) && (j < m);
-                    double Mij = ok ? acc[jj][q] : 0.0;
-                    if constexpr (DIST == 0 && KERN == 0) {
-                        // SE: every derivative is (coordinate difference) x k x constant; constants applied at the end
-                        double kv;
-                        if (offdiag) kv = Kp[(size_t)(ok ? i : 0) * mp + (ok ? j : 0)];
-                        else kv = KernFn<0, 0>::value(kp, xi[q], xjv);
-                        double g = Mij * kv;
-                        gc_tr += (i == j) ? Mij : 0.0;
-                        gc_sv += wgt * g;
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            double delta = xjv[d] - xi[q][d];
-                            double gd = g * delta;
-                            colsum[jj][d] += gd;
-                            rowsum[q][d] -= offdiag ? gd : 0.0;
-                            gc_l[d] += wgt * gd * delta;
-                        }
-                    } else {
-                        if (ok) {
-                            double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
-                            double k = KernFn<DIST, KERN>::pair(kp, xi[q], xjv, false, 0.0, dkdxi, dkdxj, dkdl);
-                            if (i != j) {
-#pragma unroll
-                                for (int d = 0; d < 3; ++d) {
-                                    colsum[jj][d] += Mij * dkdxj[d];
-                                    if (offdiag) rowsum[q][d] += Mij * dkdxi[d];
-                                }
-                            } else {
-                                gc_tr += Mij;
-                            }
-                            gc_sv += wgt * Mij * k;
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) gc_l[d] += wgt * Mij * dkdl[d];
-                        }
-                    }
-                }
-            }
-            // row sums: over the 16 columns of the lane group, then lane lr == d stores component d
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double rs[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    rs[d] = row16_sum(rowsum[q][d]);
-                    if constexpr (DIST == 0 && KERN == 0) rs[d] *= -2.0 / (kp.ls[d] * kp.ls[d]);
-                }
-                if (lr < 3) {
-                    double v = (lr == 0) ? rs[0] : ((lr == 1) ? rs[1] : rs[2]);
-                    pl.rowpart[((roff + 16 * I + lg + 4 * q) * MAX_TB + JB) * XPAD + lr] = v;
-                }
-            }
-        }
-    }
-    // ---- column sums: over the 4 lane groups, then over the 4 waves ----
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            double v = colsum[jj][d];
-            if constexpr (DIST == 0 && KERN == 0) v *= -2.0 / (kp.ls[d] * kp.ls[d]);
-            v += shfl_xor_d(v, 16);
-            v += shfl_xor_d(v, 32);
-            if (lg == 0) red[wave][16 * jj + lr][d] = v;
-        }
-    if constexpr (DIST == 0 && KERN == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gc_l[d] *= 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]);
-    }
-    double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
-    if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
-    }
-    __syncthreads();
-    {
-        int jc = tid >> 2, d = tid & 3;          // 64 columns x 4
-        int j = 64 * JB + jc;
-        if (j < mp) {
-            double v = 0.0;
-            if (d < 3) v = red[0][jc][d] + red[1][jc][d] + red[2][jc][d] + red[3][jc][d];
-            pl.gXu[(roff + j) * XPAD + d] = v;
-        }
-    }
-    if (tid < GC_SLOTS) {
-        double v = 0.0;
-        if (tid < 5) v = gcred[0][tid] + gcred[1][tid] + gcred[2][tid] + gcred[3][tid];
-        pl.gcpart[((size_t)u * ut.max_T + JB) * GC_SLOTS + tid] = v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_mtile + k_gred: k_grad2 split in two so that the MFMA half carries no reduction state (half the
-// registers -> twice the resident workgroups to hide the operand staging) and the reduction half is a
-// plain streaming kernel.
+// k_mtile + k_gred: the MFMA half carries no reduction state (few registers -> 4 resident workgroups per CU to
+// hide the operand staging) and the reduction half is a plain streaming kernel.
 // k_mtile: one workgroup per 64x64 block pair (IB >= JB) of one unit: M_IJ = At_I^T At_J - dy sum_k W_kI^T W_kJ
-// for its (up to) 16 lower-triangle tiles, staged exactly as in k_grad2 (diagonal blocks stage their 64
-// columns once), written to the M pool.
+// for its (up to) 16 lower-triangle tiles: 16-row chunks of the stacked operand [W ; At] (both row-major, leading
+// dimension mp) are staged in LDS (two register sets keep chunks c+1 and c+2 in flight, one barrier per chunk;
+// diagonal blocks stage their 64 columns once); wave w owns row tile I = 4 IB + w against the four J tiles (1 A read
+// + 4 B reads per 4 MFMAs); the W chunks come first, the accumulators are then scaled by -dy and the At chunks
+// continue in the same registers.  Tiles go to the M pool.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams kp) {
     __shared__ double chunk[2][16 * G2_LD];
@@ -1869,7 +963,9 @@ __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams 
 
 // k_gred: workgroup = (unit, 64-column block JB), wave w owns the row tiles I = 4 IB + w of every block IB >= JB.
 // Streams the lower-triangle tiles of M and K (coalesced 128-B rows), accumulates column sums in registers
-// over the whole walk and writes row sums per block through rowpart, exactly like k_grad2's epilogue.
+// over the whole walk and writes row sums per block through rowpart (folded into gXu by k_gx_finalize in fixed
+// order).  k values of strictly-lower tiles are read back from the K/U pool (the Cholesky only overwrites the upper
+// triangle); only diagonal tiles re-evaluate exp().
 template <int DIST, int KERN>
 __global__ __launch_bounds__(256, 2) void k_gred(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double red[4][64][4];
@@ -2045,7 +1141,7 @@ __global__ void k_gx_finalize(UnitTab ut, Pools pl, int total_rows) {
 // out = [ll | gradX (n x dx) | gradC (2 + ndfn)]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
-                                                  int want_gx, int want_gc, int gc_blocks, double *out) {
+                                                  int want_gx, int want_gc, double *out) {
     int dx = kp.dx;
     if (blockIdx.x == 0) {
         __shared__ double red[256][6];
@@ -2061,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
                 acc[0] += w * ll;
                 if (want_gc) {
                     int T = pad16(m) >> 4;
-                    int nJ = gc_blocks ? ((T + 3) >> 2) : T;   // k_grad2 writes one partial per 64-column block
+                    int nJ = (T + 3) >> 2;   // k_gred writes one partial per 64-column block
                     double g[5] = {0, 0, 0, 0, 0};
                     for (int J = 0; J < nJ; ++J) {
                         const double *gp = pl.gcpart + ((size_t)u * ut.max_T + J) * GC_SLOTS;
@@ -2102,13 +1198,7 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// A/B switches for kernel generations (bring-up and interleaved timing only): env var set and != "0".
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
-
-static bool variant_flag(const char *name) {
-    const char *v = getenv(name);
-    return v && v[0] && v[0] != '0';
-}
 
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
     if (total_rows == 0) return;
@@ -2120,137 +1210,64 @@ void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx,
     hipLaunchKernelGGL(k_gather_x, dim3((total_rows + 255) / 256), dim3(256), 0, s, ut.upt, X, p.Xu, dx, total_rows);
 }
 
-template <int D, int K>
-static void fill_t(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
-    int nt64 = (16 * ut.max_T + 63) / 64;
-    hipLaunchKernelGGL((k_fill<D, K>), dim3(nt64 * nt64, ut.n_ids), dim3(256), 0, s, ut, p, kp, nt64);
-}
-
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
-    if (!variant_flag("GPRF_FILL_V1")) {
-        int nt = (16 * ut.max_T + 63) / 64;
-        dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
-        if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill2<0, 0>), grid, dim3(256), 0, s, ut, p, kp);
-        else hipLaunchKernelGGL((k_fill2<1, 1>), grid, dim3(256), 0, s, ut, p, kp);
-        return;
-    }
-    if (dist_id == 0 && kern_id == 0) fill_t<0, 0>(ut, p, kp, s);
-    else fill_t<1, 1>(ut, p, kp, s);
+    int nt = (16 * ut.max_T + 63) / 64;
+    dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
+    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp);
+    else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp);
 }
 
 void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
-    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256) * sizeof(double);
+    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    if (variant_flag("GPRF_POTRF_V3") && ut.max_T <= 17) {
-        int T = ut.max_T;
-        size_t lds3 = (size_t)(16 * (16 * T + 16) + 256 + 16 + 16 * 17 + 16 * T) * sizeof(double) +
-                      (size_t)(T * (T + 1) / 2) * sizeof(int);
-        static size_t lds3_set = 0;
-        if (lds3 > 48 * 1024 && lds3 > lds3_set) {
-            (void)hipFuncSetAttribute((const void *)k_potrf3<22>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            (void)hipFuncSetAttribute((const void *)k_potrf3<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            lds3_set = lds3;
-        }
-        const char *ab3 = getenv("GPRF_POTRF_ABLATE");
-        int abl3 = ab3 ? atoi(ab3) : 0;
-        if (T <= 12) hipLaunchKernelGGL((k_potrf3<12>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p, abl3);
-        else hipLaunchKernelGGL((k_potrf3<22>), dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds3, s, ut, p, abl3);
-        return;
-    }
-    if (!variant_flag("GPRF_POTRF_V1")) {
-        size_t lds2 = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
-        static size_t lds2_set = 0;
-        if (lds2 > 48 * 1024 && lds2 > lds2_set) {
-            (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            lds2_set = lds2;
-        }
-        const char *ab = getenv("GPRF_POTRF_ABLATE");   // timing experiments only (results are wrong)
-        const char *pad = getenv("GPRF_POTRF_LDSPAD");  // experiment: extra LDS to lower the residency
-        size_t lds2p = lds2 + (pad ? (size_t)atoi(pad) : 0);
-        if (lds2p > 48 * 1024 && lds2p > lds2_set) {
-            (void)hipFuncSetAttribute((const void *)k_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p);
-            lds2_set = lds2p;
-        }
-        hipLaunchKernelGGL(k_potrf2, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds2p, s, ut, p, ab ? atoi(ab) : 0);
-        return;
-    }
-    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p);
+    const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
+    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, (st && st[0] == '1') ? 1 : 0);
 }
 
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
-    if (ut.max_T <= SOLVE2_MAXT && !variant_flag("GPRF_SOLVE_V1")) {
-        dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 4 + 3) / 4));
-        dim3 grid4(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
-        if (ut.max_T <= 12 && !variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve4<12, 3>), grid4, dim3(256), 0, s, ut, p);
-        else if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve2<12, 3>), grid, dim3(256), 0, s, ut, p);
-        else if (variant_flag("GPRF_SOLVE_V2")) hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
-        else if (!variant_flag("GPRF_SOLVE_V2")) { hipLaunchKernelGGL((k_solve4<18, 2>), grid4, dim3(256), 0, s, ut, p); return; }
-        else hipLaunchKernelGGL((k_solve2<18, 2>), grid, dim3(256), 0, s, ut, p);
+    if (ut.max_T <= SOLVE_PANEL_MAXT) {
+        dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
+        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve_panel<12, 3>), grid, dim3(256), 0, s, ut, p);
+        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 2>), grid, dim3(256), 0, s, ut, p);
         return;
     }
+    // units of more than 288 points: accumulators no longer fit the register budget -> LDS-broadcast form
     hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_ids), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
 }
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
-    if (!variant_flag("GPRF_AT_V1")) {
-        if (variant_flag("GPRF_AT_V2"))
-            hipLaunchKernelGGL(k_at2, dim3((ut.max_T + 3) / 4, ut.n_ids), dim3(256), 0, s, ut, p);
-        else
-            hipLaunchKernelGGL(k_at3, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
-        return;
-    }
-    hipLaunchKernelGGL(k_at, dim3(ut.max_T, ut.n_ids), dim3(256), 0, s, ut, p);
+    hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
 }
 
-bool grad_uses_blocks() { return !variant_flag("GPRF_GRAD_V1"); }
-
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s) {
-    if (!grad_uses_blocks() || total_rows == 0) return;
+    if (total_rows == 0) return;
     hipLaunchKernelGGL(k_gx_finalize, dim3((total_rows * 4 + 255) / 256), dim3(256), 0, s, ut, p, total_rows);
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
                  int total_rows, hipStream_t s) {
+    (void)total_rows;
     if (ut.n_ids == 0 || ut.max_T == 0) return;
-    if (grad_uses_blocks() && !variant_flag("GPRF_GRAD_V2")) {
-        int TBm = (ut.max_T + 3) / 4;
-        hipLaunchKernelGGL(k_mtile, dim3(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2)), dim3(256), 0, s, ut, p, kp);
-        dim3 gridr(xcd_grid(ut.n_ids, TBm));
-        if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_gred<0, 0>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
-        else hipLaunchKernelGGL((k_gred<1, 1>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
-        return;
-    }
-    if (grad_uses_blocks()) {
-        dim3 grid2(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4));
-        const char *ab = getenv("GPRF_GRAD_ABLATE");   // timing experiments only (results are wrong)
-        int ablate = ab ? atoi(ab) : 0;
-        if (dist_id == 0 && kern_id == 0)
-            hipLaunchKernelGGL((k_grad2<0, 0>), grid2, dim3(256), 0, s, ut, p, kp, want_gc, ablate);
-        else
-            hipLaunchKernelGGL((k_grad2<1, 1>), grid2, dim3(256), 0, s, ut, p, kp, want_gc, ablate);
-        return;
-    }
-    dim3 grid(ut.max_T, ut.n_ids);
-    if (dist_id == 0 && kern_id == 0)
-        hipLaunchKernelGGL((k_grad<0, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-    else
-        hipLaunchKernelGGL((k_grad<1, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    int TBm = (ut.max_T + 3) / 4;
+    hipLaunchKernelGGL(k_mtile, dim3(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2)), dim3(256), 0, s, ut, p, kp);
+    dim3 gridr(xcd_grid(ut.n_ids, TBm));
+    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_gred<0, 0>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
+    else hipLaunchKernelGGL((k_gred<1, 1>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
 }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s) {
     long work = (long)n * kp.dx;
     int blocks = 1 + (int)((work + 255) / 256);
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc,
-                       grad_uses_blocks() ? 1 : 0, out);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out);
 }
 
 }  // namespace gprf

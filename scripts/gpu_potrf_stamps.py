@@ -1,7 +1,7 @@
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["GPRF_POTRF_ABLATE"] = "16"
+os.environ["GPRF_POTRF_STAMPS"] = "1"
 from gprf_amd import GPCov, Blocker, grid_centers
 from gprf_amd.gprf import GPRF
 rng = np.random.RandomState(1)
@@ -13,7 +13,7 @@ ctx = g._ctx
 for _ in range(3): ctx.debug_run(X, 1)
 nt, nl = ctx.num_units()
 rows = np.array([ctx.debug_fetch(l, 6) for l in range(nl)])
-v3 = bool(os.environ.get("GPRF_POTRF_V3"))
+v3 = False
 tc = 5 if v3 else 4
 for T in (7, 13, 17):
     sel = rows[rows[:, tc] == T]

@@ -13,7 +13,8 @@ def find(sub, pat):
 
 
 def short(name):
-    for k in ("k_fill", "k_potrf", "k_solve", "k_at", "k_grad", "k_assemble", "k_gather_x", "k_gather_y"):
+    for k in ("k_fill", "k_potrf", "k_solve_panel", "k_solve", "k_at", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
+              "k_gather_x", "k_gather_y"):
         if k in name:
             return k
     return name[:40]
