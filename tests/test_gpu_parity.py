@@ -220,6 +220,36 @@ def test_update_X_fast_reblocking_path_equals_callable_path():
     fast.close(); slow.close()
 
 
+@pytest.mark.parametrize("dx,dy,sizes", [(1, 1, [5, 17, 40]), (3, 64, [33, 64, 16, 1, 90]), (2, 13, [100, 3, 129, 31]),
+                                         (3, 7, [200, 150]), (2, 50, [257, 255])])
+def test_random_shapes_against_oracle(dx, dy, sizes):
+    """SE kernel with 1-3 input dimensions, 1..64 output columns (64 = the padded width), ragged block sizes incl.
+    tile-boundary cases (16, 64, 255/257 -> pair of 512), chain of pairs + one long-range pair."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(100 * dx + dy)
+    n = sum(sizes)
+    X = rng.rand(n, dx)
+    Y = rng.randn(n, dy)
+    perm = rng.permutation(n)
+    cuts = np.cumsum([0] + sizes)
+    blocks = [np.sort(perm[cuts[i]:cuts[i + 1]]) for i in range(len(sizes))]
+    nbrs = [(i, i - 1) for i in range(1, len(sizes))]
+    if len(sizes) > 2:
+        nbrs.append((len(sizes) - 1, 0))
+    ls = list(0.2 + 0.3 * rng.rand(dx))
+    g = GPRF(X, Y, None, GPCov([1.7], ls, "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=nbrs)
+    r = GPRFRef(X, Y, None, OC([1.7], ls, "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=nbrs)
+    a = g.llgrad(grad_X=True, grad_cov=True)
+    b = r.llgrad(grad_X=True, grad_cov=True)
+    assert a[1].shape == (n, dx) and a[2].shape == (1, 2 + dx)
+    assert np.isclose(a[0], b[0], rtol=1e-11)
+    assert _close(a[1], b[1], 1e-9) and np.allclose(a[2], b[2], rtol=1e-8, atol=1e-8 * np.abs(b[2]).max())
+    g.close()
+
+
 def test_two_shards_on_one_gpu_sum_to_full():
     """The multi-GPU decomposition, exercised on one device: shard (0,2) + shard (1,2) partials add up to
     the unsharded result; device-resident evaluation path (gprf_eval_device)."""
