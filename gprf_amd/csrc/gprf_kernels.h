@@ -7,7 +7,7 @@
 namespace gprf {
 
 constexpr int TILE = 16;          // MFMA f64 16x16x4 tile edge
-constexpr int MAX_MP = 512;       // largest padded unit (GPRF_MAX_UNIT)
+constexpr int MAX_MP = 1024;       // largest padded unit (GPRF_MAX_UNIT)
 constexpr int MAX_T = MAX_MP / TILE;
 constexpr int YPAD = 64;          // dy padded to 4 column tiles
 constexpr int XPAD = 4;           // dx padded (dx <= 3)

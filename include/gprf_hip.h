@@ -47,7 +47,7 @@ typedef struct gprf_ctx gprf_ctx;
 #define GPRF_KERN_MATERN32 1  /* "matern32": k = sv * (1 + sqrt3 r) exp(-sqrt3 r) */
 
 /* Largest unit (block, or concatenated block pair) the kernels accept, in points. */
-#define GPRF_MAX_UNIT 512
+#define GPRF_MAX_UNIT 1024
 
 /* Replaces GPRF.__init__ (gprf.py:85-117) + the VectorTree construction (gprf.py:109).
  * n points, dx input dims (2 or 3), dy output columns; device = HIP device ordinal. */

@@ -34,3 +34,41 @@ def test_lbfgs_trace_follows_oracle():
     err1 = np.mean(np.linalg.norm(rx.reshape(-1, 2) - sd.SX, axis=1))
     assert err1 < err0
     g.close()
+
+
+@pytest.mark.parametrize("local_dist,nblocks", [(1.0, 4), (0.1, 9)])
+def test_lbfgs_reproduces_published_trace(published, local_dist, nblocks):
+    """The reference's published optimisation trace (gprf_results.tgz, n=2000): the first L-BFGS-B objective values
+    driven by the HIP path equal the published lines to the printed 2 decimals, and so do the mean location errors
+    (8 decimals) — end-to-end parity of objective, gradient, priors and the optimiser interface."""
+    from gprf_amd.synthetic import SampledData
+    from gprf_amd import grid_centers
+    from gprf_amd.objective import Objective
+    ntrain = 2000
+    sd = SampledData(n=ntrain + 500, ntrain=ntrain, lscale=6 / np.sqrt(ntrain), obs_std=2 / np.sqrt(ntrain), yd=50, seed=0)
+    sd.set_centers(grid_centers(nblocks))
+    rec = published["2000_2500_%d_0.134164_0.044721_%s_50_l-bfgs-b_x_-1_0.0100_s0_gprf0" % (nblocks, "%.4f" % local_dist)]
+    g = sd.build_gprf(local_dist=local_dist)
+    obj = Objective(g, sd.X_obs, None, sd)
+    xs = []
+
+    class _Stop(Exception):
+        pass
+
+    def f(x):
+        xs.append(x.copy())
+        v = obj(x)
+        if len(xs) >= len(rec["steps"]):
+            raise _Stop
+        return v
+    try:
+        scipy.optimize.minimize(f, obj.full0, jac=True, method="l-bfgs-b", options={"ftol": 1e-6, "maxiter": 200})
+    except _Stop:
+        pass
+    assert len(xs) == len(rec["steps"])
+    for k, step in enumerate(rec["steps"]):
+        assert "%.2f" % obj.trace[k][2] == step["objective"], (k, obj.trace[k][2], step["objective"])
+        err = np.mean(np.sqrt(np.sum((xs[k].reshape(-1, 2) - sd.SX) ** 2, axis=1)))
+        assert "%.8f" % err == step["mean_loc_err"]
+        assert "%.8f" % sd.x_prior(xs[k])[0] == step["x_prior"]
+    g.close()

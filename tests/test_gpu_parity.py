@@ -133,16 +133,17 @@ def test_not_pd_even_with_jitter_raises():
 def test_unit_too_large_is_refused():
     from gprf_amd.gprf import GPRF
     from gprf_amd import GPCov, _capi
-    X = np.random.RandomState(0).rand(600, 2)
-    Y = np.zeros((600, 2))
-    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), 0.01, block_idxs=[np.arange(600)], neighbors=[])
-    with pytest.raises(_capi.GprfHipError, match="at most 512"):
+    X = np.random.RandomState(0).rand(1100, 2)
+    Y = np.zeros((1100, 2))
+    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), 0.01, block_idxs=[np.arange(1100)], neighbors=[])
+    with pytest.raises(_capi.GprfHipError, match="at most 1024"):
         g.llgrad()
     g.close()
 
 
-def test_max_size_unit_512():
-    """Largest supported unit: a 256+256 pair (mp = 512, 32 tiles)."""
+def test_large_units_512_and_1000():
+    """Large units: a 256+256 pair (32 tiles), then a 500+500 pair (63 tiles; the reference's n=2000 / 4-block
+    runs have such units) — the generic k_solve path and the widest k_potrf panel."""
     from gprf_amd.gprf import GPRF
     from gprf_amd import GPCov
     from oracle.gprf_ref import GPRFRef
@@ -153,6 +154,15 @@ def test_max_size_unit_512():
     blocks = [np.arange(0, 256), np.arange(256, 512)]
     g = GPRF(X, Y, None, GPCov([1.0], [0.1, 0.1], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
     r = GPRFRef(X, Y, None, OC([1.0], [0.1, 0.1], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
+    a = g.llgrad(grad_X=True, grad_cov=True)
+    b = r.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(a[0], b[0], rtol=1e-12) and _close(a[1], b[1], 1e-10) and np.allclose(a[2], b[2], rtol=1e-9)
+    g.close()
+    X = rng.rand(1000, 2)
+    Y = rng.randn(1000, 5)
+    blocks = [np.arange(0, 500), np.arange(500, 1000)]
+    g = GPRF(X, Y, None, GPCov([1.0], [0.08, 0.08], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
+    r = GPRFRef(X, Y, None, OC([1.0], [0.08, 0.08], "euclidean", "se"), 0.05, block_idxs=blocks, neighbors=[(1, 0)])
     a = g.llgrad(grad_X=True, grad_cov=True)
     b = r.llgrad(grad_X=True, grad_cov=True)
     assert np.isclose(a[0], b[0], rtol=1e-12) and _close(a[1], b[1], 1e-10) and np.allclose(a[2], b[2], rtol=1e-9)
