@@ -115,8 +115,10 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1":   # the latter: exercise the RCCL path on one GPU
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gprf_amd import grid_centers, _capi
@@ -310,7 +312,7 @@ def main():
         ev.g.close()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
