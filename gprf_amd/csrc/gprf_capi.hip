@@ -87,9 +87,14 @@ struct gprf_ctx {
 
     // device state
     DevBuf<double> d_X, d_Y, d_out;
-    DevBuf<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_info, d_row_unit;
-    DevBuf<int64_t> d_matoff, d_slot_ptr;
-    DevBuf<double> d_weight, d_jitter, d_slot_w;
+    // tables: views into the single staged table buffer d_tab (see rebuild_units)
+    template <typename T> struct View { T *p = nullptr; void release() { p = nullptr; } };
+    View<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_row_unit, d_ids;
+    View<int64_t> d_matoff, d_slot_ptr;
+    View<double> d_weight, d_jitter, d_slot_w;
+    DevBuf<char> d_tab;
+    PinBuf<char> h_tab;
+    DevBuf<int32_t> d_info;
     DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_M, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
@@ -103,7 +108,6 @@ struct gprf_ctx {
     hipEvent_t gev_start = nullptr, gev_done[MAX_GROUPS] = {};
     bool groups_ready = false;
     int group_begin[MAX_GROUPS + 1] = {};   // ranges into d_ids
-    DevBuf<int32_t> d_ids;
 
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
@@ -117,6 +121,7 @@ struct gprf_ctx {
     double stage_ms_sum[GPRF_N_STAGES] = {};
     double stage_ms_last[GPRF_N_STAGES] = {};
     bool eval_pending = false;
+    hipEvent_t ev_tables = nullptr;   // recorded on the context stream after the table upload + Y gather
 };
 
 namespace {
@@ -294,24 +299,13 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     size_t nl1 = (size_t)std::max(nl, 1);
-    HIP_TRY(c, c->d_ids.reserve(nl1));
-    HIP_TRY(c, c->d_m.reserve(nl1));
-    HIP_TRY(c, c->d_rowoff.reserve(nl1));
-    HIP_TRY(c, c->d_matoff.reserve(nl1));
-    HIP_TRY(c, c->d_weight.reserve(nl1));
-    HIP_TRY(c, c->d_jitter.reserve(nl1));
     HIP_TRY(c, c->d_logdet.reserve(nl1));
     HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
     HIP_TRY(c, c->d_info.reserve(nl1));
     HIP_TRY(c, c->d_dbg.reserve(nl1 * 8));
     HIP_TRY(c, c->h_info.reserve(nl1));
     HIP_TRY(c, c->d_gcpart.reserve(nl1 * (size_t)std::max(maxT, 1) * GC_SLOTS));
-    HIP_TRY(c, c->d_upt.reserve((size_t)rows + 1));
-    HIP_TRY(c, c->d_row_unit.reserve((size_t)rows + 1));
     HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * MAX_TB * XPAD + 1));
-    HIP_TRY(c, c->d_slot_ptr.reserve((size_t)c->n + 1));
-    HIP_TRY(c, c->d_slot_row.reserve(slot_row.size() + 1));
-    HIP_TRY(c, c->d_slot_w.reserve(slot_w.size() + 1));
     HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_M.reserve((size_t)mat + 1));
@@ -322,31 +316,45 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1));
     HIP_TRY(c, c->d_gXu.reserve((size_t)rows * XPAD + 1));
 
-    // the uploads below read pageable vectors that die at return -> synchronous copies
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (nl > 0) {
-        HIP_TRY(c, hipMemcpy(c->d_m.p, c->l_m.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_ids.p, ids.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_rowoff.p, c->l_rowoff.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_matoff.p, c->l_matoff.data(), nl * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_weight.p, weight.data(), nl * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_jitter.p, jitter.data(), nl * sizeof(double), hipMemcpyHostToDevice));
-    }
-    if (rows > 0) {
-        HIP_TRY(c, hipMemcpy(c->d_upt.p, upt.data(), (size_t)rows * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_row_unit.p, row_unit.data(), (size_t)rows * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(c, hipMemcpy(c->d_slot_ptr.p, slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    if (!slot_row.empty()) {
-        HIP_TRY(c, hipMemcpy(c->d_slot_row.p, slot_row.data(), slot_row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_slot_w.p, slot_w.data(), slot_w.size() * sizeof(double), hipMemcpyHostToDevice));
+    // ONE staged upload: every table is packed (256-byte aligned) into one pinned buffer and copied with a
+    // single asynchronous H2D on the context stream (ten small synchronous copies cost ~0.25 ms per re-blocking)
+    HIP_TRY(c, hipStreamSynchronize(s));     // the previous staging buffer / tables may still be in use
+    {
+        struct Seg { const void *src; size_t bytes; void **dst; };
+        Seg segs[] = {
+            {c->l_m.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_m.p},
+            {ids.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_ids.p},
+            {c->l_rowoff.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_rowoff.p},
+            {c->l_matoff.data(), (size_t)nl * sizeof(int64_t), (void **)&c->d_matoff.p},
+            {weight.data(), (size_t)nl * sizeof(double), (void **)&c->d_weight.p},
+            {jitter.data(), (size_t)nl * sizeof(double), (void **)&c->d_jitter.p},
+            {upt.data(), (size_t)rows * sizeof(int32_t), (void **)&c->d_upt.p},
+            {row_unit.data(), (size_t)rows * sizeof(int32_t), (void **)&c->d_row_unit.p},
+            {slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), (void **)&c->d_slot_ptr.p},
+            {slot_row.data(), slot_row.size() * sizeof(int32_t), (void **)&c->d_slot_row.p},
+            {slot_w.data(), slot_w.size() * sizeof(double), (void **)&c->d_slot_w.p},
+        };
+        size_t total = 0;
+        for (auto &sg : segs) total += (sg.bytes + 255) & ~(size_t)255;
+        total += 256;
+        HIP_TRY(c, c->d_tab.reserve(total));
+        HIP_TRY(c, c->h_tab.reserve(total));
+        size_t off = 0;
+        for (auto &sg : segs) {
+            if (sg.bytes) memcpy(c->h_tab.p + off, sg.src, sg.bytes);
+            *sg.dst = (void *)(c->d_tab.p + off);
+            off += (sg.bytes + 255) & ~(size_t)255;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_tab.p, c->h_tab.p, off, hipMemcpyHostToDevice, s));
     }
     // Y rows of every unit (Y never changes; membership does)
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
     launch_gather_y(ut, pl, c->d_Y.p, c->dy, (int)rows, s);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(s));  // the evaluation may be enqueued on a caller's stream
+    // an evaluation enqueued on a caller's stream waits for this event instead of a host sync (enqueue_eval)
+    if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_tables, s));
     c->units_dirty = false;
     return GPRF_OK;
 }
@@ -380,6 +388,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         int rc = rebuild_units(c);
         if (rc != GPRF_OK) return rc;
     }
+    if (s != c->stream && c->ev_tables) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_tables, 0));
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
     KParams kp = make_kparams(c);
@@ -531,7 +540,8 @@ int gprf_destroy(gprf_ctx *c) {
             (void)hipEventDestroy(c->gev_done[g]);
         }
     }
-    c->d_ids.release();
+    c->d_tab.release(); c->h_tab.release();
+    if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;
