@@ -46,3 +46,28 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     print("== PMC pass %s: per-launch averages ==" % sub)
     for nm in sorted(agg):
         print("%-12s " % nm + "  ".join("%s=%.4g" % (c, agg[nm][c] / max(cnt[nm][c], 1)) for c in sorted(agg[nm])))
+
+
+# per-launch HBM traffic of the largest-grid (north-star) launches of each kernel:
+# bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md: the counters are in KiB; on gfx950 FETCH_SIZE
+# reads exactly half of a wide coalesced stream -> doubled; WRITE_SIZE is exact).  Written as JSON for bench.py.
+import json
+traffic = {}
+vals = defaultdict(lambda: defaultdict(list))
+for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for f in find(sub, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            nm = short(r.get("Kernel_Name", ""))
+            if nm.startswith("k_") and r.get("Counter_Name") == cname:
+                vals[nm][(cname, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+print("== HBM traffic per launch, largest grid of each kernel (KiB counters; read side x2 on gfx950) ==")
+for nm in sorted(vals):
+    grids = sorted({g for (_, g) in vals[nm]})
+    g = grids[-1]
+    fe = vals[nm].get(("FETCH_SIZE", g), [0.0]); wr = vals[nm].get(("WRITE_SIZE", g), [0.0])
+    fetch_kib, write_kib = sum(fe) / len(fe), sum(wr) / len(wr)
+    traffic[nm] = {"grid": g, "fetch_KiB": fetch_kib, "write_KiB": write_kib,
+                   "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
+    print("%-14s grid %8d  FETCH_SIZE %10.0f KiB  WRITE_SIZE %10.0f KiB  -> %.1f MB" % (nm, g, fetch_kib, write_kib, traffic[nm]["bytes_per_launch"] / 1e6))
+with open(os.path.join(out, "traffic.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1, sort_keys=True)
