@@ -21,6 +21,7 @@
 //                        gC[t]   = 1/2 sum_pq M[p,q] dK_pq/dtheta_t  (gprf.py:577-584),
 //                        ll      = -1/2 ||Z||_F^2 - dy sum log U_kk - 1/2 dy m log 2pi (gprf.py:542-544).
 #include "gprf_kernels.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -317,14 +318,44 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double p, double *d_out, double *
     *d_out = d;
 }
 
-// upper Cholesky of one 16x16 tile held one column per lane (s[i] = C[i][lr]); returns the first bad pivot
-// (1-based row within the tile) or 0; *dk / *rdk = this lane's diagonal entry and its reciprocal
+// compile-time counted loop: f(std::integral_constant<int, i>) for i in [B, E) — the DPP lane selectors below
+// are instruction immediates
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// 64-bit DPP (gfx90a+: DP-ALU DPP, row_newbcast only): every lane reads lane L of ITS row of 16 lanes.
+// s_nop 1 = the two wait states a DPP read needs after a VALU write of the source register (the assembler
+// does not see into inline asm, so the hazard is covered here).
+template <int L>
+__device__ __forceinline__ double bcast16(double src) {
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
+    return r;
+}
+// acc -= (lane L's src) * mul   in one instruction
+template <int L>
+__device__ __forceinline__ void fnma_bcast16(double &acc, double src, double mul) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(src), "v"(mul), "n"(L));
+}
+
+// upper Cholesky of one 16x16 tile held one column per lane (s[i] = C[i][lr], replicated in the wave's four
+// rows of 16 lanes); returns the first bad pivot (1-based row within the tile) or 0; *dk / *rdk = this lane's
+// diagonal entry and its reciprocal.  Pivot k: every lane fetches the pivot by DPP broadcast and computes its
+// root redundantly; the rank-1 update s[i] -= U[k][i] U[k][lr] takes U[k][i] from lane i by DPP inside the
+// FMA — no v_readlane, no SGPR traffic on the 16-pivot chain.
 __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk, double *rdk) {
     int bad = 0;
     double mydiag = 1.0, myrd = 1.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        double pkk = readlane_d(s[k], k);
+    static_for<0, 16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double pkk = bcast16<k>(s[k]);
         bool isbad = !(pkk > 0.0);
         bad = (isbad && bad == 0) ? (k + 1) : bad;
         pkk = isbad ? 1.0 : pkk;
@@ -332,11 +363,13 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk
         sqrt_and_rsqrt(pkk, &d, &rd);
         double ukc = (lr > k) ? s[k] * rd : ((lr == k) ? d : 0.0);
         s[k] = ukc;
-#pragma unroll
-        for (int i = k + 1; i < 16; ++i) s[i] -= readlane_d(ukc, i) * ukc;
+        static_for<k + 1, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            fnma_bcast16<i>(s[i], ukc, ukc);
+        });
         mydiag = (lr == k) ? d : mydiag;
         myrd = (lr == k) ? rd : myrd;
-    }
+    });
     *dk = mydiag;
     *rdk = myrd;
     return bad;
@@ -416,12 +449,19 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
                 double *Cc = U + (size_t)(16 * j) * mp + col;
 #pragma unroll
                 for (int a = 0; a < 16; ++a) x[a] = Cc[(size_t)a * mp];
+                // U_jj one column per lane (in each row of 16 lanes): U[c][a] reaches the FMA by DPP broadcast from
+                // lane a — 16 LDS reads up front instead of one per FMA
+                double uc[16], rdl = rdt[lr];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    x[c] *= rdt[c];
-#pragma unroll
-                    for (int a = c + 1; a < 16; ++a) x[a] -= Ud[c * 16 + a] * x[c];
-                }
+                for (int c = 0; c < 16; ++c) uc[c] = Ud[c * 16 + lr];
+                static_for<0, 16>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    x[c] *= bcast16<c>(rdl);
+                    static_for<c + 1, 16>([&](auto ac) {
+                        constexpr int a = decltype(ac)::value;
+                        fnma_bcast16<a>(x[a], uc[c], x[c]);
+                    });
+                });
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
                     Cc[(size_t)a * mp] = x[a];
