@@ -4,7 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libgprf_hip.so")
+# GPRF_LIB: diagnostic builds (ablation / profile variants) live next to the product library under another name
+LIB = os.environ.get("GPRF_LIB") or os.path.join(HERE, "libgprf_hip.so")
 SOURCES = ["gprf_kernels.hip", "gprf_capi.hip"]
 HEADERS = ["gprf_kernels.h", os.path.join("..", "..", "include", "gprf_hip.h")]
 
@@ -24,6 +25,8 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
            "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    # diagnostic builds: GPRF_BUILD_DEFS="-DGPRF_PROFILE" compiles the in-kernel cycle stamps in
+    cmd[1:1] = os.environ.get("GPRF_BUILD_DEFS", "").split()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

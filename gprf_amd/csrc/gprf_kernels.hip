@@ -337,45 +337,108 @@ __device__ __forceinline__ double bcast16(double src) {
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
     return r;
 }
-// acc -= (lane L's src) * mul   in one instruction
+// acc -= (lane L's src) * mul   in one instruction.  No wait states inside: the caller guarantees that `src`
+// was not written by a VALU instruction in the two issue slots before (LDS / memory loads are covered by
+// s_waitcnt; after a VALU definition use dpp_src_ready()).
 template <int L>
 __device__ __forceinline__ void fnma_bcast16(double &acc, double src, double mul) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc)
-        : "v"(src), "v"(mul), "n"(L));
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
 }
+// two wait states after the VALU definition of a value that DPP instructions are about to read
+__device__ __forceinline__ void dpp_src_ready(double &src) { asm volatile("s_nop 1" : "+v"(src)); }
 
 // upper Cholesky of one 16x16 tile held one column per lane (s[i] = C[i][lr], replicated in the wave's four
 // rows of 16 lanes); returns the first bad pivot (1-based row within the tile) or 0; *dk / *rdk = this lane's
 // diagonal entry and its reciprocal.  Pivot k: every lane fetches the pivot by DPP broadcast and computes its
 // root redundantly; the rank-1 update s[i] -= U[k][i] U[k][lr] takes U[k][i] from lane i by DPP inside the
 // FMA — no v_readlane, no SGPR traffic on the 16-pivot chain.
-__device__ __forceinline__ int diag_factor16(double (&s)[16], int lr, double *dk, double *rdk) {
-    int bad = 0;
-    double mydiag = 1.0, myrd = 1.0;
+__device__ __forceinline__ int diag_factor16(double (&s)[16], int lr_in, double *dk, double *rdk) {
+    double myrd = 1.0;
     static_for<0, 16>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+        // an opaque copy of the lane index per pivot: otherwise the 32 lane masks (lr > k, lr == k) are all
+        // computed up front, hoisted out of the caller's step loop and spilled (64 SGPRs)
+        int lr = lr_in;
+        asm volatile("" : "+v"(lr));
+        // a non-positive (or NaN) pivot turns into NaN here and poisons every later pivot: found after the loop
         double pkk = bcast16<k>(s[k]);
-        bool isbad = !(pkk > 0.0);
-        bad = (isbad && bad == 0) ? (k + 1) : bad;
-        pkk = isbad ? 1.0 : pkk;
         double d, rd;
         sqrt_and_rsqrt(pkk, &d, &rd);
         double ukc = (lr > k) ? s[k] * rd : ((lr == k) ? d : 0.0);
+        dpp_src_ready(ukc);
         s[k] = ukc;
         static_for<k + 1, 16>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             fnma_bcast16<i>(s[i], ukc, ukc);
         });
-        mydiag = (lr == k) ? d : mydiag;
         myrd = (lr == k) ? rd : myrd;
     });
+    // this lane's diagonal entry: row lr of its own column
+    double mydiag = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        int lr = lr_in;
+        asm volatile("" : "+v"(lr));
+        mydiag = (lr == i) ? s[i] : mydiag;
+    }
     *dk = mydiag;
     *rdk = myrd;
-    return bad;
+    // first pivot that failed = lowest lane (of the 16 columns) whose diagonal is not a positive number
+    unsigned long long badmask = __ballot(!(mydiag > 0.0)) & 0xffffull;
+    return badmask ? __builtin_ctzll(badmask) + 1 : 0;
 }
 
-__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools pl, int stamps) {
+// shared tail of the Cholesky kernels: V_jj = U_jj^-1 for every diagonal tile (wanted by the triangular-solve
+// kernels' MFMA form; 4 tiles per wave at a time, lane (lg, lr) = row lr of tile 4*grp + lg, by the column
+// operations that reduce U_jj to I) and log|K| = 2 sum log U_kk (gpy_linalg.py:234) in a fixed order.
+// `stage` is >= 256*T doubles of LDS that are free by now.
+template <int NWAVES>
+__device__ __forceinline__ void potrf_epilogue(const double *U, double *V, double *stage, const double *dvals,
+                                               double *lred, int mp, int T, int u, const Pools &pl) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lr = lane & 15, lg = lane >> 4;
+    for (int grp = wave; 4 * grp < T; grp += NWAVES) {
+        int jt = 4 * grp + lg;
+        double *Us = stage + jt * 256;
+        if (jt < T) {
+            const double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Us[i * 16 + lr] = Ujj[(size_t)i * mp + lr];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (jt < T) {
+            double v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                int lrc = lr;
+                asm volatile("" : "+v"(lrc));       // keep the 16 lane masks from living in SGPRs all at once
+                v[c] = (c == lrc) ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] *= 1.0 / Us[k * 16 + k];
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) v[i] -= Us[k * 16 + i] * v[k];
+            }
+            double *Vj = V + (size_t)jt * 256 + lr * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Vj[c] = v[c];
+        }
+    }
+    double part = 0.0;
+    for (int r = threadIdx.x; r < mp; r += NWAVES * 64) part += log(dvals[r]);
+    for (int off = 32; off >= 1; off >>= 1) part += shfl_xor_d(part, off);
+    if (lane == 0) lred[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NWAVES; ++w) t += lred[w];
+        pl.logdet[u] = 2.0 * t;
+        pl.info[u] = 0;
+    }
+}
+
+__global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools pl, int stamps, int reg_maxT) {
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
@@ -388,6 +451,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         return;
     }
     int mp = pad16(m), T = mp >> 4;
+    if (T <= reg_maxT) return;            // k_potrf_reg's units
     int ldp = mp + ((T & 1) ? 0 : 16);
     double *P = lds;                      // [16][ldp] row panel j of U
     double *Ud = P + 16 * ldp;            // [16][16]  U_jj
@@ -405,7 +469,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
             double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                double uv = (i <= lr) ? s[i] : 0.0;
+                double uv = s[i];                   // the factor left 0 below the diagonal
                 Ujj[(size_t)i * mp + lr] = uv;
                 Ud[i * 16 + lr] = uv;
             }
@@ -538,44 +602,443 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
         return;
     }
-    // ---- V_jj = U_jj^-1 for every diagonal tile: 4 tiles per wave at a time, lane (lg, lr) = row lr of
-    //      tile 4*grp + lg;  apply to I the column operations that reduce U_jj to I ----
-    for (int grp = wave; 4 * grp < T; grp += POTRF_WAVES) {
-        int jt = 4 * grp + lg;
-        double *Us = P + jt * 256;            // the panel buffer is free now: 256 T <= 16 ldp doubles
-        if (jt < T) {
-            const double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
+    potrf_epilogue<POTRF_WAVES>(U, V, P, dvals, lred, mp, T, u, pl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_potrf_reg's accumulator tiles live in EXPLICITLY NUMBERED AGPRs: tile S = a[8S : 8S+7], D layout (lane
+// (lg, lr), register pair q = element [lg + 4q][lr]).  They are invisible to the compiler on purpose: as C++
+// values it copies them between the VGPR and AGPR halves around every use (240 v_accvgpr_read per step) or
+// spills them.  Every access is one of the volatile asm blocks below (volatile asm keeps program order); the
+// kernel declares the range with atile_reserve() and holds no other AGPR values (tests/ checks the ISA).
+// Inline asm is invisible to the hazard recogniser, so the wait states are written out:
+//   * VALU write (v_accvgpr_write, operand moves) -> MFMA read: 2          -> s_nop 1 before the MFMAs
+//   * MFMA f64 16x16x4 result -> same-tuple srcC of the next MFMA: 0        (back-to-back accumulate)
+//   * MFMA f64 16x16x4 result -> VALU / LDS read: 18                        -> atile_settle() / trailing s_nop's
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atile_reserve() {
+    asm volatile("; accumulator tiles: a[0:239]" ::: "a0", "a1", "a238", "a239");
+}
+__device__ __forceinline__ void atile_settle() { asm volatile("s_nop 15\n\ts_nop 3"); }
+
+template <int S>
+__device__ __forceinline__ void atile_set(const double (&v)[4]) {
+    asm volatile("v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1\n\t"
+                 "v_accvgpr_write_b32 a[%10], %2\n\tv_accvgpr_write_b32 a[%11], %3\n\t"
+                 "v_accvgpr_write_b32 a[%12], %4\n\tv_accvgpr_write_b32 a[%13], %5\n\t"
+                 "v_accvgpr_write_b32 a[%14], %6\n\tv_accvgpr_write_b32 a[%15], %7"
+                 :
+                 : "v"(__double2loint(v[0])), "v"(__double2hiint(v[0])), "v"(__double2loint(v[1])),
+                   "v"(__double2hiint(v[1])), "v"(__double2loint(v[2])), "v"(__double2hiint(v[2])),
+                   "v"(__double2loint(v[3])), "v"(__double2hiint(v[3])), "n"(8 * S), "n"(8 * S + 1), "n"(8 * S + 2),
+                   "n"(8 * S + 3), "n"(8 * S + 4), "n"(8 * S + 5), "n"(8 * S + 6), "n"(8 * S + 7));
+}
+template <int S>
+__device__ __forceinline__ void atile_get(double (&v)[4]) {
+    int w[8];
+    asm volatile("v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\t"
+                 "v_accvgpr_read_b32 %2, a[%10]\n\tv_accvgpr_read_b32 %3, a[%11]\n\t"
+                 "v_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\t"
+                 "v_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]"
+                 : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])
+                 : "n"(8 * S), "n"(8 * S + 1), "n"(8 * S + 2), "n"(8 * S + 3), "n"(8 * S + 4), "n"(8 * S + 5),
+                   "n"(8 * S + 6), "n"(8 * S + 7));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) Us[i * 16 + lr] = Ujj[(size_t)i * mp + lr];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (jt < T) {
-            double v[16];
+    for (int q = 0; q < 4; ++q) v[q] = __hiloint2double(w[2 * q + 1], w[2 * q]);
+}
+// tile S += sum_t a[t]^T b[t]  (four chained MFMAs), in two pieces: the caller puts the next tile's operand
+// fetch (scalar decode, address adds, LDS reads) between them, where it issues for free while the first MFMA
+// occupies the pipe — with one wave per SIMD nothing else would hide it
+template <int S>
+__device__ __forceinline__ void atile_mfma_first(const double (&a)[4], const double (&b)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]"
+                 :
+                 : "v"(a[0]), "v"(b[0]), "n"(8 * S), "n"(8 * S + 7));
+}
+template <int S>
+__device__ __forceinline__ void atile_mfma_rest(const double (&a)[4], const double (&b)[4]) {
+    asm volatile("v_mfma_f64_16x16x4_f64 a[%6:%7], %0, %1, a[%6:%7]\n\t"
+                 "v_mfma_f64_16x16x4_f64 a[%6:%7], %2, %3, a[%6:%7]\n\t"
+                 "v_mfma_f64_16x16x4_f64 a[%6:%7], %4, %5, a[%6:%7]"
+                 :
+                 : "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "n"(8 * S), "n"(8 * S + 7));
+}
+// the same on a VGPR tile (the diagonal tiles, staged through LDS): c += sum_t a[t]^T b[t]; the result is
+// settled (readable) on return
+__device__ __forceinline__ void mfma4_vgpr(d4 &c, const double (&a)[4], const double (&b)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %4, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %5, %6, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %7, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 3"
+                 : "+v"(c)
+                 : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+}
+
+constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the register-resident kernel takes
+constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
+// ------------------------------------------------------------------------------------------------
+// k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
+// chip (T <= reg_maxT tiles per edge).  The trailing matrix never goes back to memory: the strictly-upper
+// tiles, enumerated row-major, are dealt cyclically to waves 1..7 (tile idx -> wave 1 + idx%7, slot idx/7)
+// and live in their MFMA accumulators, so that every row panel and every trailing update is spread over all
+// seven; the T diagonal tiles live in LDS (Dt).  Step j:
+//   waves 1..7: their tiles of row j -> LDS panel -> one column per lane -> forward substitution (DPP
+//               broadcast of U_jj) -> LDS panel + global U
+//   barrier
+//   wave 0    : look-ahead — Dt[j+1] -= P_{j+1}^T P_{j+1}, factor, publish U_{j+1,j+1}
+//   waves 1..7: acc[slot] -= P_i^T P_k for their live tiles and Dt[i] -= P_i^T P_i for i >= j+2 (tile i by wave
+//               1 + i%7), both MFMA operands from the LDS panel
+//   barrier
+// Global traffic is one read of K's upper triangle and one write of U; the per-step chain is
+// substitution + factor with no memory latency in it.
+// ------------------------------------------------------------------------------------------------
+// The accumulator tiles are register-indexed by the SLOT number, which is a run-time value in the step loops:
+// a switch (one jump table) selects the asm stub with that tile's register numbers.
+#define GPRF_CASES32(M)                                                                                     \
+    M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
+    M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+template <int RW, int SLOTS>
+__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT) {
+    static_assert(8 * SLOTS <= 240, "atile_reserve() covers a[0:239]");
+    extern __shared__ double lds[];
+    __shared__ int s_fail;
+    __shared__ double lred[RW];
+#ifdef GPRF_PROFILE
+    unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    int u = ut.ids[blockIdx.x];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    if (T > reg_maxT) return;             // k_potrf's units
+    if (m == 0) {
+        if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
+        return;
+    }
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lr = lane & 15, lg = lane >> 4;
+    // fixed panel pitch (an odd multiple of 16 doubles: the k-major MFMA operand reads are conflict free):
+    // every LDS row offset below is an instruction immediate
+    constexpr int ldp = POTRF_REG_LDP;
+    double *P = lds;                      // [16][ldp] row panel j of U
+    double *Ud = P + 16 * ldp;            // [16][16]  U_jj
+    double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
+    double *dvals = rdt + 16;             // [16 T]    diagonal of U
+    double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
+    double *U = pl.U + ut.mat_off[u];
+    double *V = pl.V + (size_t)ut.row_off[u] * 16;
+    if (threadIdx.x == 0) s_fail = 0;
+    unsigned glane = (unsigned)(lg * mp + lr);
+    int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
+
+    // slot -> tile (uniform per wave): 32 * tile row + tile column, or -1; kept in lanes 0..SLOTS-1 of one
+    // VGPR and fetched with v_readlane where needed (15 live SGPRs would crowd out the row pointers)
+    // workers: waves 1..7 while their 7 * SLOTS slots hold the strictly-upper tiles; the largest units deal to
+    // all eight waves (wave 0 then has trailing work after its factor)
+    const int nw = (T * (T - 1) / 2 <= (RW - 1) * SLOTS) ? RW - 1 : RW;
+    const int wk = wave - (RW - nw);              // worker index, -1 for a pure-factor wave 0
+    int pkv = -1;
+    {
+        int idx = wk + nw * lane, i = 0, rs = 0, rl = T - 1;   // lane s decodes slot s
+        while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
+        if (wk >= 0 && rl > 0 && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
+    }
+#define PK(s) __builtin_amdgcn_readlane(pkv, s)
+    atile_reserve();
+    // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
+    // (volatile) accumulator write, which nothing is moved across
+    constexpr int PRO_BATCH = 10;
+    static_for<0, (SLOTS + PRO_BATCH - 1) / PRO_BATCH>([&](auto bc) {
+        constexpr int B0 = decltype(bc)::value * PRO_BATCH;
+        double kv[PRO_BATCH][4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = (c == lr) ? 1.0 : 0.0;
+        for (int i = 0; i < PRO_BATCH; ++i) {
+            // uniform row pointer + one 32-bit lane offset: global_load with an SGPR base; unconditional (a
+            // branch per slot serialises the loads)
+            int pks = (B0 + i < SLOTS) ? PK(B0 + i < SLOTS ? B0 + i : 0) : -1;
+            int pc = pks < 0 ? 0 : pks;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                v[k] *= 1.0 / Us[k * 16 + k];
-#pragma unroll
-                for (int i = k + 1; i < 16; ++i) v[i] -= Us[k * 16 + i] * v[k];
+            for (int q = 0; q < 4; ++q) {
+                const double *Cs = U + (size_t)(16 * (pc >> 5) + 4 * q) * mp + 16 * (pc & 31);
+                kv[i][q] = -Cs[glane];            // the accumulators hold MINUS the trailing tile
             }
-            double *Vj = V + (size_t)jt * 256 + lr * 16;
+        }
+        static_for<0, PRO_BATCH>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (B0 + I < SLOTS) atile_set<B0 + I>(kv[I]);
+        });
+    });
+    // diagonal tiles -> LDS
+    for (int i = wave; i < T; i += RW) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) Vj[c] = v[c];
+        for (int q = 0; q < 4; ++q) {
+            const double *Cs = U + (size_t)(16 * i + 4 * q) * mp + 16 * i;
+            Dt[i * 256 + 64 * q + dlane] = Cs[glane];
         }
     }
-    // ---- log-determinant ----
-    double part = 0.0;
-    for (int r = threadIdx.x; r < mp; r += POTRF_WAVES * 64) part += log(dvals[r]);
-    for (int off = 32; off >= 1; off >>= 1) part += shfl_xor_d(part, off);
-    if (lane == 0) lred[wave] = part;
+
+    // wave 0: factor tile jt (in Dt, row-major) and publish it in LDS: Ud / rdt / dvals
+    auto factor_publish = [&](int jt) {
+        __builtin_amdgcn_wave_barrier();
+        double s[16], dk, rdk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = Dt[jt * 256 + r * 16 + lr];
+#ifndef GPRF_ABL_NOFACTOR
+        int bad = diag_factor16(s, lr, &dk, &rdk);
+#else
+        int bad = 0;
+        dk = rdk = s[3];
+#endif
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ud[i * 16 + lr] = s[i];   // the factor left 0 below the diagonal
+            rdt[lr] = rdk;
+            dvals[16 * jt + lr] = dk;
+            if (bad && lane == 0) s_fail = 16 * jt + bad;
+        }
+    };
+    // Dt[i] -= P_i^T P_i
+    auto diag_update = [&](int i) {
+        d4 t;
+        double a[4], na[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = Dt[i * 256 + 64 * q + dlane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = P[(4 * k + lg) * ldp + 16 * i + lr];
+            na[k] = -a[k];
+        }
+        mfma4_vgpr(t, na, a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q];
+    };
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < POTRF_WAVES; ++w) t += lred[w];
-        pl.logdet[u] = 2.0 * t;
-        pl.info[u] = 0;
+    if (wave == 0) factor_publish(0);
+    __syncthreads();
+
+    // diagnostic builds only (GPRF_BUILD_DEFS=-DGPRF_PROFILE; the stamps cost registers):
+    // GPRF_POTRF_STAMPS=1: wave 0's [idle | barrier | look-ahead + factor | barrier];
+    // GPRF_POTRF_STAMPS=2: wave 1's [dump | panel loads | substitution | stores | barrier | trailing | barrier]
+#ifdef GPRF_PROFILE
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    bool stamp = stamps == 1 && wave == 0;      // wave-uniform: the accumulators stay in SGPRs
+    bool stamp2 = stamps == 2 && wave == 1;
+    bool stamp3 = stamps == 3 && wave == 1;     // wave 1's phase 2: [panel copy | diagonal tiles | trailing chain | rest]
+#define GPRF_STAMPX(on, k)                                                \
+    if (on) {                                                             \
+        unsigned long long tn = __builtin_amdgcn_s_memtime();             \
+        tacc[k] += tn - tprev;                                            \
+        tprev = tn;                                                       \
     }
+#define GPRF_STAMP(k) GPRF_STAMPX(stamp, k)
+#define GPRF_STAMP2(k) GPRF_STAMPX(stamp2, k)
+#define GPRF_STAMP3(k) GPRF_STAMPX(stamp3, k)
+#else
+    constexpr bool stamp = false, stamp2 = false, stamp3 = false;
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    (void)tacc; (void)tprev; (void)stamps;
+#define GPRF_STAMP(k)
+#define GPRF_STAMP2(k)
+#define GPRF_STAMP3(k)
+#endif
+    if (stamp || stamp2 || stamp3) tprev = __builtin_amdgcn_s_memtime();
+#ifdef GPRF_PROFILE
+    unsigned long long t_loop = tprev;
+#endif
+    // smallest slot of this worker whose tile index wk + nw * s is >= r
+    auto first_slot = [&](int r) {
+        int d = r - wk + nw - 1;
+        int q = d <= 0 ? 0 : (nw == RW ? d / RW : d / (RW - 1));
+        return __builtin_amdgcn_readfirstlane(q < SLOTS ? q : SLOTS);
+    };
+    const int s_end = first_slot(T * (T - 1) / 2);
+    for (int j = 0; j + 1 < T; ++j) {
+#ifndef GPRF_ABL
+        if (s_fail) break;
+#endif
+        // keep the per-slot tile coordinates and LDS addresses from being hoisted out of the step loop (they are
+        // loop invariant, and 18 slots of them would push the accumulators out of the register file)
+        int lb = lg * ldp + lr;
+        asm volatile("" : "+v"(lb));
+        asm volatile("" : "+v"(pkv));
+        // this worker's slots [s_lo, s_hi) hold tiles of row j, [s_hi, s_end) the live tiles below it
+        const int s_lo = first_slot(j * T - (j * (j + 1)) / 2);
+        const int s_hi = first_slot((j + 1) * T - ((j + 1) * (j + 2)) / 2);
+        if (wave == 0) {
+            // U_jj (published in LDS by the last look-ahead) -> global, off the critical path
+            for (int e = lane; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
+        }
+        if (wk >= 0) {
+            // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
+#ifndef GPRF_ABL_NODUMP
+#pragma unroll 1
+            for (int sl = s_lo; sl < s_hi; ++sl) {
+                int pks = __builtin_amdgcn_readlane(pkv, sl);
+                double tv[4];
+#define GPRF_CASE(S)                                   \
+    case S:                                            \
+        if constexpr (S < SLOTS) atile_get<S>(tv);     \
+        break;
+                switch (sl) {
+                    GPRF_CASES32(GPRF_CASE)
+                    default: break;
+                }
+#undef GPRF_CASE
+                // stored as held (negated); the substitution's load negates
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[lb + (4 * q) * ldp + 16 * (pks & 31)] = tv[q];
+            }
+#endif
+            __builtin_amdgcn_wave_barrier();
+            GPRF_STAMP2(0)
+            // they are tiles k0, k0+nw, ... of the row: lane row lg takes the lg-th, one column per lane
+            int rs = j * T - (j * (j + 1)) / 2;
+            int k0 = j + 1 + ((((wk - rs) % nw) + nw) % nw);
+            // (a second pass only when a worker holds more than four tiles of the row)
+#pragma unroll 1
+            for (int k = k0 + nw * lg; __any(k < T); k += 4 * nw) {
+              if (k < T) {
+                int col = 16 * k + lr;
+                double x[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) x[a] = -P[a * ldp + col];   // the dump left minus the tile
+                double rdl = rdt[lr];
+                double uc[3] = {Ud[lr], Ud[16 + lr], 0.0};   // row c of U_jj, fetched two rows ahead
+                GPRF_STAMP2(1)
+#ifndef GPRF_ABL_NOSUBST
+                static_for<0, 16>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if (c + 2 < 16) uc[(c + 2) % 3] = Ud[(c + 2) * 16 + lr];
+                    x[c] *= bcast16<c>(rdl);
+                    static_for<c + 1, 16>([&](auto ac) {
+                        constexpr int a = decltype(ac)::value;
+                        fnma_bcast16<a>(x[a], uc[c % 3], x[c]);
+                    });
+                });
+#endif
+                GPRF_STAMP2(2)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) P[a * ldp + col] = x[a];
+              }
+            }
+        }
+        GPRF_STAMP(0)
+        GPRF_STAMP2(3)
+        lds_barrier();
+        GPRF_STAMP(1)
+        GPRF_STAMP2(4)
+        if (wave == 0) {
+            diag_update(j + 1);
+            factor_publish(j + 1);
+        }
+        GPRF_STAMP3(3)
+        if (wk >= 0) {
+            // the solved row panel -> global U first (rows dealt to the workers, coalesced along the row): the
+            // stores retire under the MFMA work below; nothing reads them back before the epilogue, so the
+            // step barriers do not wait for them
+#ifndef GPRF_ABL_NOCOPY
+            for (int a = wk; a < 16; a += nw) {
+                double *Urow = U + (size_t)(16 * j + a) * mp;
+                int c0 = 16 * (j + 1) + lane;
+                double pv[4];                 // mp <= 256: at most four 64-column chunks; LDS reads first
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = (c0 + 64 * i < mp) ? P[a * ldp + c0 + 64 * i] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c0 + 64 * i < mp) Urow[c0 + 64 * i] = pv[i];
+            }
+            GPRF_STAMP3(0)
+            // diagonal tiles beyond the look-ahead one: tile i by worker i % nw
+            for (int i = j + 2 + (wk + nw * T - (j + 2)) % nw; i < T; i += nw) diag_update(i);
+#endif
+            GPRF_STAMP3(1)
+            // live tiles: slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS panel
+            // before slot S's four MFMAs issue
+            auto opnd_load = [&](int pks, double (&oa)[4], double (&ob)[4]) {
+                int pc = pks < 0 ? 0 : pks;
+                const double *Pa = P + lb + 16 * (pc >> 5);
+                const double *Pk = P + lb + 16 * (pc & 31);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    oa[t] = Pa[(4 * t) * ldp];
+                    ob[t] = Pk[(4 * t) * ldp];
+                }
+            };
+#ifndef GPRF_ABL_NOTRAIL
+            if (s_hi < s_end) {
+                // walked from the LAST slot down: the slot index stays a compile-time constant (register numbers)
+                // in straight-line code, the dead slots (below s_hi) are never visited, and one compare per tile
+                // ends the walk
+                double oa[2][4], ob[2][4];
+                opnd_load(__builtin_amdgcn_readlane(pkv, s_end - 1), oa[0], ob[0]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { oa[1][t] = oa[0][t]; ob[1][t] = ob[0][t]; }
+                bool done = false;
+                static_for<0, SLOTS>([&](auto sc) {
+                    constexpr int S = SLOTS - 1 - decltype(sc)::value;
+                    int hi = s_hi, end = s_end;
+                    asm volatile("" : "+s"(hi), "+s"(end));     // (keeps the 2 * SLOTS compares from being hoisted)
+                    if (!done && S < end) {
+                        if (S < hi) {
+                            done = true;
+                        } else {
+                            atile_mfma_first<S>(oa[S & 1], ob[S & 1]);
+                            if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
+                            atile_mfma_rest<S>(oa[S & 1], ob[S & 1]);
+                        }
+                    }
+                });
+                atile_settle();      // before anything (the next step's dump) reads the tiles
+            }
+#endif
+        }
+        GPRF_STAMP(2)
+        GPRF_STAMP2(5)
+        GPRF_STAMP3(2)
+        lds_barrier();
+        GPRF_STAMP(3)
+        GPRF_STAMP2(6)
+    }
+#ifdef GPRF_PROFILE
+    unsigned long long t_loopend = __builtin_amdgcn_s_memtime();
+#endif
+    if (stamp && lane == 0) {
+        for (int k = 0; k < 4; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+        pl.dbg[(size_t)u * 8 + 4] = (double)T;
+    }
+    if (stamp3 && lane == 0) {
+        for (int k = 0; k < 4; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+        pl.dbg[(size_t)u * 8 + 4] = (double)T;
+    }
+    if (stamp2 && lane == 0) {
+        for (int k = 0; k < 7; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+        pl.dbg[(size_t)u * 8 + 7] = (double)T;
+    }
+#undef GPRF_STAMP
+#undef GPRF_STAMP2
+#undef GPRF_STAMP3
+#undef PK
+    __syncthreads();
+    if (s_fail) {
+        if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
+        return;
+    }
+    if (wave == 0) {
+        int jt = T - 1;
+        for (int e = lane; e < 256; e += 64) U[(size_t)(16 * jt + (e >> 4)) * mp + 16 * jt + (e & 15)] = Ud[e];
+    }
+    __syncthreads();    // the epilogue reads U_jj back from global
+#ifndef GPRF_ABL_NOEPI
+    potrf_epilogue<RW>(U, V, P, dvals, lred, mp, T, u, pl);
+#endif
+#ifdef GPRF_PROFILE
+    if (stamp && lane == 0) {   // [5] prologue, [6] epilogue cycles
+        pl.dbg[(size_t)u * 8 + 5] = (double)(t_loop - t_start);
+        pl.dbg[(size_t)u * 8 + 6] = (double)(__builtin_amdgcn_s_memtime() - t_loopend);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1258,16 +1721,37 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp);
 }
 
+constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGPRs + 256 AGPRs each
+constexpr int POTRF_REG_SLOTS = 30;   // 3 workers x 30 slots >= 13*12/2, 4 x 30 = 16*15/2 strictly-upper tiles (240 AGPRs)
+constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 points
+
 void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
+    const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
+    int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
+    const char *rg = getenv("GPRF_POTRF_REG");      // A/B switch while the register-resident kernel is tuned
+    int reg_maxT = (rg && rg[0] == '0') ? 0 : POTRF_REG_MAXT;
+    if (reg_maxT) {
+        int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
+        size_t lds = (size_t)(16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        static size_t lds_set_r = 0;
+        if (lds > 48 * 1024 && lds > lds_set_r) {
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_set_r = lds;
+        }
+        hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
+                           ut, p,
+                           stamps, reg_maxT);
+        if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
+    }
     size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
-    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, (st && st[0] == '1') ? 1 : 0);
+    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, stamps, reg_maxT);
 }
 
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {

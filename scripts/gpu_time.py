@@ -1,4 +1,5 @@
-"""Stage timing on a C3-shaped problem (random Y): python scripts/gpu_time.py [reps]"""
+"""Stage timing on a C3-shaped problem (random Y): python scripts/gpu_time.py [reps]
+WORLD=N times rank 0's shard of an N-rank job (partial sums, no all-reduce)."""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +10,8 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20, tag=""):
     rng = np.random.RandomState(1)
     X = rng.rand(n, 2); Y = rng.randn(n, dy)
     b = Blocker(grid_centers(nb)); blocks = b.block_clusters(X); nbrs = b.neighbors() if pairs else []
-    g = GPRF(X, Y, None, GPCov([1.0], [lscale, lscale], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs)
+    g = GPRF(X, Y, None, GPCov([1.0], [lscale, lscale], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs,
+             shard=(0, int(os.environ["WORLD"])) if os.environ.get("WORLD") else None)
     if os.environ.get("RAW"):
         # ablation runs produce garbage (possibly NOT_PD): time the raw C-ABI call and ignore the status
         g._push_neighbors(nbrs)
