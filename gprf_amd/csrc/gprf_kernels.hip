@@ -407,19 +407,26 @@ __device__ __forceinline__ void potrf_epilogue(const double *U, double *V, doubl
         }
         __builtin_amdgcn_wave_barrier();
         if (jt < T) {
-            double v[16];
+            // the same column operations as the row-panel substitution, on the identity: lane lr holds column lr
+            // of its tile's U_jj (uc) and row lr of V; U[k][i] reaches the FMA by DPP broadcast from lane i
+            double v[16], uc[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 int lrc = lr;
                 asm volatile("" : "+v"(lrc));       // keep the 16 lane masks from living in SGPRs all at once
                 v[c] = (c == lrc) ? 1.0 : 0.0;
+                uc[c] = Us[c * 16 + lr];
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                v[k] *= 1.0 / Us[k * 16 + k];
-#pragma unroll
-                for (int i = k + 1; i < 16; ++i) v[i] -= Us[k * 16 + i] * v[k];
-            }
+            double rdl = 1.0 / Us[lr * 16 + lr];
+            dpp_src_ready(rdl);
+            static_for<0, 16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                v[k] *= bcast16<k>(rdl);
+                static_for<k + 1, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    fnma_bcast16<i>(v[i], uc[k], v[k]);
+                });
+            });
             double *Vj = V + (size_t)jt * 256 + lr * 16;
 #pragma unroll
             for (int c = 0; c < 16; ++c) Vj[c] = v[c];
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
 //   * MFMA f64 16x16x4 result -> VALU / LDS read: 18                        -> atile_settle() / trailing s_nop's
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void atile_reserve() {
-    asm volatile("; accumulator tiles: a[0:239]" ::: "a0", "a1", "a238", "a239");
+    asm volatile("; accumulator tiles: a[0:255]" ::: "a0", "a1", "a254", "a255");
 }
 __device__ __forceinline__ void atile_settle() { asm volatile("s_nop 15\n\ts_nop 3"); }
 
@@ -702,7 +709,7 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
     M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
 template <int RW, int SLOTS>
 __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT) {
-    static_assert(8 * SLOTS <= 240, "atile_reserve() covers a[0:239]");
+    static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[RW];
@@ -722,8 +729,9 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     // fixed panel pitch (an odd multiple of 16 doubles: the k-major MFMA operand reads are conflict free):
     // every LDS row offset below is an instruction immediate
     constexpr int ldp = POTRF_REG_LDP;
-    double *P = lds;                      // [16][ldp] row panel j of U
-    double *Ud = P + 16 * ldp;            // [16][16]  U_jj
+    double *P0 = lds;                     // [2][16][ldp] row panel j of U in buffer j & 1: a pure-factor wave 0
+    double *Ud = P0 + 2 * 16 * ldp;       //   writes panel j-1 back to global while panel j is being solved
+                                          // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *dvals = rdt + 16;             // [16 T]    diagonal of U
     double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
@@ -733,43 +741,50 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     unsigned glane = (unsigned)(lg * mp + lr);
     int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
 
-    // slot -> tile (uniform per wave): 32 * tile row + tile column, or -1; kept in lanes 0..SLOTS-1 of one
-    // VGPR and fetched with v_readlane where needed (15 live SGPRs would crowd out the row pointers)
-    // workers: waves 1..7 while their 7 * SLOTS slots hold the strictly-upper tiles; the largest units deal to
-    // all eight waves (wave 0 then has trailing work after its factor)
-    const int nw = (T * (T - 1) / 2 <= (RW - 1) * SLOTS) ? RW - 1 : RW;
-    const int wk = wave - (RW - nw);              // worker index, -1 for a pure-factor wave 0
-    int pkv = -1;
+    // Dealing the strictly-upper tiles (row-major index idx) to the waves: in every period of dP = 3 dm + 1
+    // consecutive tiles, workers 1..3 take dm each (positions w, w+3, ...) and wave 0 the last one.  While the
+    // three workers' 3 * SLOTS slots hold everything (T <= 14) dm = SLOTS and the period is never completed: wave
+    // 0 only factors.  Larger units shorten the period until the workers fit; wave 0 then has trailing work after
+    // its factor, as little as possible.
+    static_assert(RW == 4, "three workers + the factor wave");
+    const int total = T * (T - 1) / 2;
+    int dm = SLOTS;
+    if (total > 3 * SLOTS) {
+        for (dm = SLOTS / 2; dm > 1; --dm) {
+            int dP = 3 * dm + 1, x = total % dP;
+            int c = (total / dP) * dm + (x + 2) / 3;
+            if ((x + 2) / 3 > dm) c = (total / dP) * dm + dm;
+            if (c <= SLOTS) break;
+        }
+    }
+    dm = __builtin_amdgcn_readfirstlane(dm);
+    const int dP = 3 * dm + 1;
+    const bool w0busy = total > 3 * SLOTS;             // wave 0 owns tiles too
+    const bool mine = wave > 0 || w0busy;
+    // tiles of this wave among idx < r
+    auto cnt = [&](int r) {
+        int q = r / dP, x = r % dP;
+        if (wave == 0) return q;
+        int c = (x - (wave - 1) + 2) / 3;
+        if (x - (wave - 1) + 2 < 0) c = 0;
+        return q * dm + (c < 0 ? 0 : (c > dm ? dm : c));
+    };
+    // lane s: slot s -> tile, 32 * tile row + tile column, or -1 (fetched with v_readlane / a shuffle where
+    // needed: 30-odd live SGPRs would crowd out the row pointers);  lane j: s_hi of step j = this wave's tiles
+    // in rows 0..j
+    int pkv = -1, shv = 0;
     {
-        int idx = wk + nw * lane, i = 0, rs = 0, rl = T - 1;   // lane s decodes slot s
+        int sl = lane;
+        int idx = (wave == 0) ? sl * dP + dP - 1 : (sl / dm) * dP + 3 * (sl % dm) + (wave - 1);
+        int i = 0, rs = 0, rl = T - 1;
         while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
-        if (wk >= 0 && rl > 0 && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
+        if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
+        int jj = lane < T - 1 ? lane : T - 1;           // rows 0..jj end at tile index (jj+1) T - (jj+1)(jj+2)/2
+        shv = mine ? cnt((jj + 1) * T - ((jj + 1) * (jj + 2)) / 2) : 0;
+        if (shv > SLOTS) shv = SLOTS;
     }
 #define PK(s) __builtin_amdgcn_readlane(pkv, s)
     atile_reserve();
-    // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
-    // (volatile) accumulator write, which nothing is moved across
-    constexpr int PRO_BATCH = 10;
-    static_for<0, (SLOTS + PRO_BATCH - 1) / PRO_BATCH>([&](auto bc) {
-        constexpr int B0 = decltype(bc)::value * PRO_BATCH;
-        double kv[PRO_BATCH][4];
-#pragma unroll
-        for (int i = 0; i < PRO_BATCH; ++i) {
-            // uniform row pointer + one 32-bit lane offset: global_load with an SGPR base; unconditional (a
-            // branch per slot serialises the loads)
-            int pks = (B0 + i < SLOTS) ? PK(B0 + i < SLOTS ? B0 + i : 0) : -1;
-            int pc = pks < 0 ? 0 : pks;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double *Cs = U + (size_t)(16 * (pc >> 5) + 4 * q) * mp + 16 * (pc & 31);
-                kv[i][q] = -Cs[glane];            // the accumulators hold MINUS the trailing tile
-            }
-        }
-        static_for<0, PRO_BATCH>([&](auto ic) {
-            constexpr int I = decltype(ic)::value;
-            if constexpr (B0 + I < SLOTS) atile_set<B0 + I>(kv[I]);
-        });
-    });
     // diagonal tiles -> LDS
     for (int i = wave; i < T; i += RW) {
 #pragma unroll
@@ -800,6 +815,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         }
     };
     // Dt[i] -= P_i^T P_i
+    double *P = P0;                       // the current step's panel buffer
     auto diag_update = [&](int i) {
         d4 t;
         double a[4], na[4];
@@ -814,8 +830,35 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q];
     };
+    auto load_tiles = [&]() {
+        // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
+        // (volatile) accumulator write, which nothing is moved across
+        constexpr int PRO_BATCH = 10;
+        static_for<0, (SLOTS + PRO_BATCH - 1) / PRO_BATCH>([&](auto bc) {
+            constexpr int B0 = decltype(bc)::value * PRO_BATCH;
+            double kv[PRO_BATCH][4];
+    #pragma unroll
+            for (int i = 0; i < PRO_BATCH; ++i) {
+                // uniform row pointer + one 32-bit lane offset: global_load with an SGPR base; unconditional (a
+                // branch per slot serialises the loads)
+                int pks = (B0 + i < SLOTS) ? PK(B0 + i < SLOTS ? B0 + i : 0) : -1;
+                int pc = pks < 0 ? 0 : pks;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double *Cs = U + (size_t)(16 * (pc >> 5) + 4 * q) * mp + 16 * (pc & 31);
+                    kv[i][q] = -Cs[glane];            // the accumulators hold MINUS the trailing tile
+                }
+            }
+            static_for<0, PRO_BATCH>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                if constexpr (B0 + I < SLOTS) atile_set<B0 + I>(kv[I]);
+            });
+        });
+    };
     __syncthreads();
+    // wave 0 factors the first diagonal tile while the workers fetch their tiles
     if (wave == 0) factor_publish(0);
+    if (mine) load_tiles();
     __syncthreads();
 
     // diagnostic builds only (GPRF_BUILD_DEFS=-DGPRF_PROFILE; the stamps cost registers):
@@ -847,13 +890,38 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 #ifdef GPRF_PROFILE
     unsigned long long t_loop = tprev;
 #endif
-    // smallest slot of this worker whose tile index wk + nw * s is >= r
-    auto first_slot = [&](int r) {
-        int d = r - wk + nw - 1;
-        int q = d <= 0 ? 0 : (nw == RW ? d / RW : d / (RW - 1));
-        return __builtin_amdgcn_readfirstlane(q < SLOTS ? q : SLOTS);
+    const int s_end = T >= 2 ? __builtin_amdgcn_readlane(shv, T - 2) : 0;
+    // solved row panel jp (LDS buffer jp & 1) -> global U, rows a0, a0 + da, ...; coalesced along the row, the LDS
+    // reads of a row issued before its stores.  Nothing reads it back before the epilogue, so no barrier waits
+    // for these stores.
+    auto copy_panel = [&](int jp, int a0, int da) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const double *Pj = P0 + (jp & 1) * 16 * ldp;
+        // two columns per lane (16-byte LDS reads and global stores: the copy is instruction-issue bound); the
+        // panel starts at a multiple of 16 columns and mp <= 256, so two 128-column chunks cover it
+        int c0 = 16 * (jp + 1) + 2 * lane;
+        bool in0 = c0 < mp, in1 = c0 + 128 < mp;
+        d2 pv[16][2];
+        // every LDS read first, then every store: a read -> wait -> store round trip per row would cost more than
+        // the rest of the step
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int a = a0 + da * r;
+            if (a < 16) {
+                if (in0) pv[r][0] = *(const d2 *)(Pj + a * ldp + c0);
+                if (in1) pv[r][1] = *(const d2 *)(Pj + a * ldp + c0 + 128);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int a = a0 + da * r;
+            if (a < 16) {
+                double *Urow = U + (size_t)(16 * jp + a) * mp;
+                if (in0) *(d2 *)(Urow + c0) = pv[r][0];
+                if (in1) *(d2 *)(Urow + c0 + 128) = pv[r][1];
+            }
+        }
     };
-    const int s_end = first_slot(T * (T - 1) / 2);
     for (int j = 0; j + 1 < T; ++j) {
 #ifndef GPRF_ABL
         if (s_fail) break;
@@ -864,13 +932,17 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         asm volatile("" : "+v"(lb));
         asm volatile("" : "+v"(pkv));
         // this worker's slots [s_lo, s_hi) hold tiles of row j, [s_hi, s_end) the live tiles below it
-        const int s_lo = first_slot(j * T - (j * (j + 1)) / 2);
-        const int s_hi = first_slot((j + 1) * T - ((j + 1) * (j + 2)) / 2);
+        asm volatile("" : "+v"(shv));
+        const int s_lo = j > 0 ? __builtin_amdgcn_readlane(shv, j - 1) : 0;
+        const int s_hi = __builtin_amdgcn_readlane(shv, j);
+        P = P0 + (j & 1) * 16 * ldp;
         if (wave == 0) {
             // U_jj (published in LDS by the last look-ahead) -> global, off the critical path
             for (int e = lane; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
+            // and, when this wave has no tiles of its own, the previous step's solved row panel
+            if (!w0busy && j > 0) copy_panel(j - 1, 0, 1);
         }
-        if (wk >= 0) {
+        if (mine) {
             // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
 #ifndef GPRF_ABL_NODUMP
 #pragma unroll 1
@@ -893,13 +965,12 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 #endif
             __builtin_amdgcn_wave_barrier();
             GPRF_STAMP2(0)
-            // they are tiles k0, k0+nw, ... of the row: lane row lg takes the lg-th, one column per lane
-            int rs = j * T - (j * (j + 1)) / 2;
-            int k0 = j + 1 + ((((wk - rs) % nw) + nw) % nw);
-            // (a second pass only when a worker holds more than four tiles of the row)
+            // lane row lg solves the lg-th of them (a second pass only when the wave holds more than four tiles
+            // of the row), one column per lane
 #pragma unroll 1
-            for (int k = k0 + nw * lg; __any(k < T); k += 4 * nw) {
-              if (k < T) {
+            for (int sl = s_lo + lg; __any(sl < s_hi); sl += 4) {
+              int k = __shfl(pkv, sl & 31, 64) & 31;    // (all lanes active here: the source lane may be in any row)
+              if (sl < s_hi) {
                 int col = 16 * k + lr;
                 double x[16];
 #pragma unroll
@@ -934,24 +1005,15 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
             factor_publish(j + 1);
         }
         GPRF_STAMP3(3)
-        if (wk >= 0) {
-            // the solved row panel -> global U first (rows dealt to the workers, coalesced along the row): the
-            // stores retire under the MFMA work below; nothing reads them back before the epilogue, so the
-            // step barriers do not wait for them
+        if (mine) {
+            // the solved row panel -> global U first when wave 0 is a worker too: the stores retire under the
+            // MFMA work below
 #ifndef GPRF_ABL_NOCOPY
-            for (int a = wk; a < 16; a += nw) {
-                double *Urow = U + (size_t)(16 * j + a) * mp;
-                int c0 = 16 * (j + 1) + lane;
-                double pv[4];                 // mp <= 256: at most four 64-column chunks; LDS reads first
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pv[i] = (c0 + 64 * i < mp) ? P[a * ldp + c0 + 64 * i] : 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c0 + 64 * i < mp) Urow[c0 + 64 * i] = pv[i];
-            }
+            if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution)
             GPRF_STAMP3(0)
-            // diagonal tiles beyond the look-ahead one: tile i by worker i % nw
-            for (int i = j + 2 + (wk + nw * T - (j + 2)) % nw; i < T; i += nw) diag_update(i);
+            // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % 3
+            if (wave > 0)
+                for (int i = j + 2 + (wave - 1 + 3 * T - (j + 2)) % 3; i < T; i += 3) diag_update(i);
 #endif
             GPRF_STAMP3(1)
             // live tiles: slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS panel
@@ -1029,9 +1091,10 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         int jt = T - 1;
         for (int e = lane; e < 256; e += 64) U[(size_t)(16 * jt + (e >> 4)) * mp + 16 * jt + (e & 15)] = Ud[e];
     }
+    if (!w0busy && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
     __syncthreads();    // the epilogue reads U_jj back from global
 #ifndef GPRF_ABL_NOEPI
-    potrf_epilogue<RW>(U, V, P, dvals, lred, mp, T, u, pl);
+    potrf_epilogue<RW>(U, V, P0, dvals, lred, mp, T, u, pl);
 #endif
 #ifdef GPRF_PROFILE
     if (stamp && lane == 0) {   // [5] prologue, [6] epilogue cycles
@@ -1722,7 +1785,7 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 }
 
 constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGPRs + 256 AGPRs each
-constexpr int POTRF_REG_SLOTS = 30;   // 3 workers x 30 slots >= 13*12/2, 4 x 30 = 16*15/2 strictly-upper tiles (240 AGPRs)
+constexpr int POTRF_REG_SLOTS = 32;   // 3 workers x 32 slots >= 14*13/2 strictly-upper tiles (all 256 AGPRs)
 constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 points
 
 void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
@@ -1733,7 +1796,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     int reg_maxT = (rg && rg[0] == '0') ? 0 : POTRF_REG_MAXT;
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
-        size_t lds = (size_t)(16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
         static size_t lds_set_r = 0;
         if (lds > 48 * 1024 && lds > lds_set_r) {
             (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
