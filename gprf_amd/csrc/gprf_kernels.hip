@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
                 }
             }
             Vl[r & 1][tid] = prev;
-            __syncthreads();
+            lds_barrier();                        // LDS only: no wait for the W / Z stores of the step before
             if (r + 1 < T) fetch(r + 1);
             if (live && r >= r0) {
                 const double *vl = Vl[r & 1] + lg * 16 + lr;
