@@ -1,0 +1,65 @@
+"""Compile-time invariants of the hand-scheduled Cholesky kernels, checked on the gfx950 ISA that hipcc emits
+(no GPU needed).  k_potrf_reg keeps its accumulator tiles in explicitly numbered AGPRs behind volatile asm:
+that is only sound while the compiler itself never touches an AGPR in that kernel and never spills."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gprf_amd", "csrc", "gprf_kernels.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "gprf_kernels.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-o", out, SRC], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def _function(lines, mangled_part):
+    start = [i for i, l in enumerate(lines) if mangled_part in l and l.startswith("_Z") and "; @" in l]
+    assert len(start) == 1, "kernel %s not found exactly once" % mangled_part
+    end = [i for i, l in enumerate(lines) if i > start[0] and ".Lfunc_end" in l][0]
+    return lines[start[0]:end]
+
+
+def _setting(lines, mangled_part, key):
+    for l in lines:
+        m = re.match(r"\s*\.set\s+(\S+)\.%s,\s*(\d+)" % key, l)
+        if m and mangled_part in m.group(1):
+            return int(m.group(2))
+    raise AssertionError("no .set %s for %s" % (key, mangled_part))
+
+
+def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa):
+    body = _function(isa, "k_potrf_regILi4ELi32")
+    inasm, outside, stubs = False, [], 0
+    for l in body:
+        if "#ASMSTART" in l:
+            inasm = True
+            continue
+        if "#ASMEND" in l:
+            inasm = False
+            continue
+        code = l.split(";")[0]
+        if inasm:
+            stubs += bool(re.search(r"\ba\[", code))
+        elif re.search(r"\ba\[?\d", code):
+            outside.append(l.strip())
+    assert stubs > 300                      # the tile stubs are there (32 tiles x set / get / MFMA)
+    assert not outside, outside[:5]         # ... and nothing else names an AGPR
+    assert not [l for l in body if "scratch_" in l]          # no spills in the step loop or anywhere else
+    assert _setting(isa, "k_potrf_regILi4ELi32", "num_agpr") == 256
+    assert _setting(isa, "k_potrf_regILi4ELi32", "num_vgpr") <= 256
+
+
+def test_generic_potrf_does_not_spill(isa):
+    body = _function(isa, "7k_potrfENS")
+    assert not [l for l in body if "scratch_" in l]
