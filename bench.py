@@ -256,7 +256,7 @@ def main():
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01b_traffic.json")))
-            key = {"potrf": "k_potrf_reg", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mtile", "fill": "k_fill"}[dom]
+            key = {"potrf": "k_potrf_reg", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 roof["traffic"] = tr[key]["bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r01b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"

@@ -10,7 +10,7 @@ from . import build as _build
 
 GPRF_OK, GPRF_NOT_PD = 0, 1
 N_STAGES = 7
-STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")   # grad = k_mtile + k_gred + k_gx_finalize
+STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")   # grad = k_mgrad + k_gx_finalize
 DIST_IDS = {"euclidean": 0, "lld": 1}
 KERN_IDS = {"se": 0, "matern32": 1}
 MAX_UNIT = 1024
@@ -255,9 +255,16 @@ class Context(object):
                     "gprf_debug_unit_shape")
         return m.value, mp.value, g.value
 
+    def max_T(self):
+        """16-row tiles per edge of the largest local unit (stride of the per-block partial pools)."""
+        _, nl = self.num_units()
+        return max([self.debug_unit_shape(l)[1] // 16 for l in range(nl)] + [0])
+
     def debug_fetch(self, l, what):
         m, mp, _ = self.debug_unit_shape(l)
-        shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,), 6: (8,)}[what]
+        tbm = max((self.max_T() + 3) // 4, 1) if what in (7, 8) else 0
+        shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,), 6: (8,),
+                 7: (mp, tbm, XPAD), 8: (mp, tbm, XPAD)}[what]
         out = np.zeros(shape)
         self._check(self.lib.gprf_debug_fetch(self.h, l, what, dptr(out), out.size), "gprf_debug_fetch")
         return out

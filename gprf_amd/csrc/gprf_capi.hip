@@ -95,7 +95,7 @@ struct gprf_ctx {
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
     DevBuf<int32_t> d_info;
-    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_M, d_dbg;
+    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
 
@@ -160,7 +160,7 @@ Pools make_pools(gprf_ctx *c) {
     Pools p;
     p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
-    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p; p.M = c->d_M.p; p.dbg = c->d_dbg.p;
+    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
     return p;
 }
 
@@ -304,11 +304,12 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_info.reserve(nl1));
     HIP_TRY(c, c->d_dbg.reserve(nl1 * 8));
     HIP_TRY(c, c->h_info.reserve(nl1));
-    HIP_TRY(c, c->d_gcpart.reserve(nl1 * (size_t)std::max(maxT, 1) * GC_SLOTS));
-    HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * MAX_TB * XPAD + 1));
+    size_t tbm = (size_t)std::max((maxT + 3) / 4, 1);      // 64-point blocks per edge of the largest local unit
+    HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
+    HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1));
+    HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1));
     HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
-    HIP_TRY(c, c->d_M.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
     HIP_TRY(c, c->d_Xu.reserve((size_t)rows * XPAD + 1));
     HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));
@@ -528,7 +529,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
     c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
-    c->d_gcpart.release(); c->d_rowpart.release(); c->d_M.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
+    c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
@@ -830,6 +831,12 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
         case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;
         case 4: src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;
         case 6: src = c->d_dbg.p + (size_t)l * 8; len = 8; break;
+        case 7: case 8: {   // per-block partials of the gradient reduction: mp x TBm x XPAD
+            int64_t tbm = std::max((c->max_T + 3) / 4, 1);
+            src = (what == 7 ? c->d_colpart.p : c->d_rowpart.p) + roff * tbm * XPAD;
+            len = mp * tbm * XPAD;
+            break;
+        }
         case 5: {
             if (out_len < 4) return GPRF_ERR_ARG;
             double zz[4];

@@ -40,17 +40,17 @@ struct UnitTab {
 struct Pools {
     double *U;     // K, overwritten by its upper Cholesky factor (row-major mp x mp per unit)
     double *W;     // U^-T (lower triangular, row-major)
-    double *M;     // k_mtile: lower-triangle tiles of M = A A^T - dy K^-1 (row-major mp x mp per unit)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
     double *Xu;    // gathered unit coordinates, XPAD per padded row
     double *Yu;    // gathered unit outputs, YPAD per padded row (zero padded)
     double *Z;     // U^-T Yu, YPAD per padded row
     double *At;    // (K^-1 Yu)^T : per unit YPAD x mp at YPAD*row_off
     double *gXu;   // per-unit-row gradient slab, XPAD per padded row
-    double *rowpart;  // k_grad2: per padded row, MAX_TB x XPAD partial row sums (one per column block)
+    double *rowpart;  // k_mgrad: per padded row, TBm x XPAD partial row sums (one per column block JB <= its block)
+    double *colpart;  // k_mgrad: per padded row, TBm x XPAD partial column sums (one per row block IB >= its block)
     double *logdet;   // per unit
     double *zzpart;   // per unit x 4 : partial sums of ||Z||_F^2 per Y column block
-    double *gcpart;   // per unit x max_T x GC_SLOTS
+    double *gcpart;   // per unit x TBm (TBm + 1) / 2 block pairs x GC_SLOTS,  TBm = ceil(max_T / 4)
     int32_t *info;    // per unit: 0 ok, k>0 = non-positive pivot at row k-1
     double *dbg;      // per unit x 8: in-kernel cycle stamps of diagnostic builds (GPRF_POTRF_ABLATE & 16)
 };

@@ -15,8 +15,8 @@
 // In that form:   K = U^T U            (upper Cholesky, U row-major)              k_potrf
 //                 W = U^-T, Z = U^-T Y (forward substitution on [I | Y])          k_solve_panel (k_solve for m > 288)
 //                 At = Z^T W = (K^-1 Y)^T                                         k_at
-//                 M = At^T At - dy * W^T W  ( = A A^T - dy K^-1 ), lower-triangle tiles       k_mtile
-//                 M reduced against dk/dx and dk/dtheta into gradX rows / gradC partials       k_gred
+//                 M = At^T At - dy * W^T W  ( = A A^T - dy K^-1 ), lower-triangle tiles,      k_mgrad
+//                 M reduced against dk/dx and dk/dtheta into gradX / gradC partials (same kernel)
 // Reference identities:  gX[p,i] = sum_q M[p,q] dk(x_p,x_q)/dx_p[i]  (gprf.py:556-573),
 //                        gC[t]   = 1/2 sum_pq M[p,q] dK_pq/dtheta_t  (gprf.py:577-584),
 //                        ll      = -1/2 ||Z||_F^2 - dy sum log U_kk - 1/2 dy m log 2pi (gprf.py:542-544).
@@ -1408,16 +1408,20 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_mtile + k_gred: the MFMA half carries no reduction state (few registers -> 4 resident workgroups per CU to
-// hide the operand staging) and the reduction half is a plain streaming kernel.
-// k_mtile: one workgroup per 64x64 block pair (IB >= JB) of one unit: M_IJ = At_I^T At_J - dy sum_k W_kI^T W_kJ
-// for its (up to) 16 lower-triangle tiles: 16-row chunks of the stacked operand [W ; At] (both row-major, leading
-// dimension mp) are staged in LDS (two register sets keep chunks c+1 and c+2 in flight, one barrier per chunk;
-// diagonal blocks stage their 64 columns once); wave w owns row tile I = 4 IB + w against the four J tiles (1 A read
-// + 4 B reads per 4 MFMAs); the W chunks come first, the accumulators are then scaled by -dy and the At chunks
-// continue in the same registers.  Tiles go to the M pool.
+// k_mgrad: one workgroup per 64x64 block pair (IB >= JB) of one unit.
+// MFMA half: M_IJ = At_I^T At_J - dy sum_k W_kI^T W_kJ for its (up to) 16 lower-triangle tiles: 16-row chunks of
+// the stacked operand [W ; At] (both row-major, leading dimension mp) are staged in LDS (two register sets keep
+// chunks c+1 and c+2 in flight, one barrier per chunk; diagonal blocks stage their 64 columns once); wave w owns
+// row tile I = 4 IB + w against the four J tiles (1 A read + 4 B reads per 4 MFMAs); the W chunks come first,
+// the accumulators are then scaled by -dy and the At chunks continue in the same registers.
+// Reduction half: the accumulator layout is exactly what the reduction wants (a lane holds 4 rows of one
+// column), so the tiles are reduced in place against dk/dx, dk/dtheta — M is never written.  A strictly-lower
+// tile gives column sums to the points of J (-> colpart[j][IB]) and row sums to the points of I (-> rowpart[i][JB],
+// DPP row reduction); k values of strictly-lower tiles are read back from the K/U pool, only diagonal tiles
+// re-evaluate exp().  k_gx_finalize folds the per-block partials in a fixed order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams kp) {
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
     int TBm = (ut.max_T + 3) >> 2;
     int slot, bp;
@@ -1432,12 +1436,13 @@ __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams 
     int IB = JB + rem;
     if (IB >= TB) return;
     int tid = threadIdx.x;
-    int lane = tid & 63, wave = tid >> 6;
+    // the wave index as a scalar: everything derived from it (row tile, which tiles exist, diagonal or not) is
+    // then uniform for the compiler too and turns into scalar branches instead of EXEC masking
+    int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lr = lane & 15, lg = lane >> 4;
     size_t roff = ut.row_off[u];
     const double *__restrict__ W = pl.W + ut.mat_off[u];
     const double *__restrict__ At = pl.At + roff * YPAD;
-    double *__restrict__ Mo = pl.M + ut.mat_off[u];
     int J0 = 4 * JB;
     int I = 4 * IB + wave;
     bool active = I < T;
@@ -1475,11 +1480,11 @@ __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams 
 #pragma unroll
         for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
     };
-    auto mma_chunk = [&](const double *buf) {
+    auto mma_chunk = [&](const double *buf, double asc) {
         const double *rowp = buf + lg * G2_LD + lr;
         double a[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = rowp[(4 * s) * G2_LD + 16 * wave];
+        for (int s = 0; s < 4; ++s) a[s] = asc * rowp[(4 * s) * G2_LD + 16 * wave];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             if (need[jj]) {
@@ -1499,16 +1504,12 @@ __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams 
         }
         __syncthreads();
         if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
+        // the -dy of the W part rides on the A operand (4 multiplies per chunk): the accumulators are never
+        // rescaled in the middle of the chunk loop
         if (c < nchW) {
-            if (active && (4 * IB + c) >= I) mma_chunk(buf);
+            if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd);
         } else {
-            if (c == nchW) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[jj][q] *= -dyd;
-            }
-            if (active) mma_chunk(buf);
+            if (active) mma_chunk(buf, 1.0);
         }
     };
     fetch0(0);
@@ -1517,187 +1518,203 @@ __global__ __launch_bounds__(256, 4) void k_mtile(UnitTab ut, Pools pl, KParams 
         step(c, pre0, true);
         if (c + 1 < nch) step(c + 1, pre1, false);
     }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        if (need[jj]) {
-            double *mp_ = Mo + (size_t)(16 * I + lg) * mp + 16 * (J0 + jj) + lr;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mp_[(size_t)(4 * q) * mp] = acc[jj][q];
-        }
-    }
-}
-
-// k_gred: workgroup = (unit, 64-column block JB), wave w owns the row tiles I = 4 IB + w of every block IB >= JB.
-// Streams the lower-triangle tiles of M and K (coalesced 128-B rows), accumulates column sums in registers
-// over the whole walk and writes row sums per block through rowpart (folded into gXu by k_gx_finalize in fixed
-// order).  k values of strictly-lower tiles are read back from the K/U pool (the Cholesky only overwrites the upper
-// triangle); only diagonal tiles re-evaluate exp().
-template <int DIST, int KERN>
-__global__ __launch_bounds__(256, 2) void k_gred(UnitTab ut, Pools pl, KParams kp, int want_gc) {
-    __shared__ double red[4][64][4];
-    __shared__ double gcred[4][8];
-    int slot, JB;
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 3) >> 2, &slot, &JB)) return;
-    int u = ut.ids[slot];
-    int m = ut.m[u];
-    int mp = pad16(m), T = mp >> 4;
-    int TB = (T + 3) >> 2;
-    if (JB >= TB) return;
-    int tid = threadIdx.x;
-    int lane = tid & 63, wave = tid >> 6;
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ Mi = pl.M + ut.mat_off[u];
+    // ---- the block pair's M tiles are in the accumulators (lane (lg, lr), acc[jj][q] = M[16 I + lg + 4q][16 (J0+jj)
+    //      + lr]); reduce them against dk/dx and dk/dtheta right here: M never goes to memory ----
+    __syncthreads();                                   // the staging buffer is reused for the reductions
+    double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
+    double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
     const double *__restrict__ Kp = pl.U + ut.mat_off[u];
     const double *__restrict__ Xu = pl.Xu + roff * XPAD;
-    int J0 = 4 * JB;
-    double colsum[4][3];
-    double xjv[4][3];
+    const int tbs = TBm;                               // stride of the per-block partials
+    double rowsum[4][3], xi[4][3];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        int j = 16 * (J0 + jj) + lr;
+    for (int q = 0; q < 4; ++q) {
+        int i = 16 * I + lg + 4 * q;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            colsum[jj][d] = 0.0;
-            xjv[jj][d] = (j < mp) ? Xu[(size_t)j * XPAD + d] : 0.0;
+            rowsum[q][d] = 0.0;
+            xi[q][d] = active ? Xu[(size_t)i * XPAD + d] : 0.0;
         }
     }
     double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
-    for (int IB = JB; IB < TB; ++IB) {
-        int I = 4 * IB + wave;
-        if (I >= T) continue;
-        double rowsum[4][3], xi[4][3];
+    double csum[4][3];
+    // SE kernel: dk/dx = -2 delta / ls^2 k, dk/dls = 2 delta^2 / ls^3 k; the factors are applied to the sums
+    // (unused dimensions have ls = 0 in KParams: factor 0 there, not inf)
+    double fx[3], fl[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        bool used = d < kp.dx;
+        fx[d] = used ? -2.0 / (kp.ls[d] * kp.ls[d]) : 0.0;
+        fl[d] = used ? 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]) : 0.0;
+    }
+    // the wave's diagonal tile (diagonal block pairs only; it is tile jj == wave): k re-evaluated from the
+    // coordinates (the pool holds U there), column sums only
+    double csd[3] = {0.0, 0.0, 0.0};
+    if (active && diagblk) {                           // wave-uniform
+        d4 md = wave == 0 ? acc[0] : (wave == 1 ? acc[1] : (wave == 2 ? acc[2] : acc[3]));
+        int j = 16 * I + lr;
+        double xj[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = 16 * I + lg + 4 * q;
+            bool ok = (i < m) && (j < m);
+            double Mij = ok ? md[q] : 0.0;
+            if constexpr (DIST == 0 && KERN == 0) {
+                double g = Mij * KernFn<0, 0>::value(kp, xi[q], xj);
+                gc_tr += (i == j) ? Mij : 0.0;
+                gc_sv += g;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                rowsum[q][d] = 0.0;
-                xi[q][d] = Xu[(size_t)i * XPAD + d];
+                for (int d = 0; d < 3; ++d) {
+                    double delta = xj[d] - xi[q][d];
+                    double gd = g * delta;
+                    csd[d] += gd;
+                    gc_l[d] += gd * delta;
+                }
+            } else {
+                if (ok) {
+                    double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
+                    double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
+                    if (i != j) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) csd[d] += Mij * dkdxj[d];
+                    } else {
+                        gc_tr += Mij;
+                    }
+                    gc_sv += Mij * k;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
+                }
             }
         }
-        // all tile loads of this row tile first (up to 32 loads in flight), then the arithmetic
-        double Mv[4][4], Kv[4][4];
+    }
+    // strictly-lower tiles: k read back from the K/U pool (the Cholesky only overwrites the upper triangle);
+    // column sums for the points of J, row sums for the points of I, everything counted twice in the theta sums
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < 4; ++jj) {
+        bool mydiag = diagblk && jj == wave;
+        double colsum[3] = {mydiag ? csd[0] : 0.0, mydiag ? csd[1] : 0.0, mydiag ? csd[2] : 0.0};
+        if (need[jj] && J0 + jj < I) {                 // wave-uniform
             int J = J0 + jj;
-            bool nd = (J <= I) && (J < T);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                size_t off = (size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr;
-                Mv[jj][q] = nd ? Mi[off] : 0.0;
-                Kv[jj][q] = (nd && I > J) ? Kp[off] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            int J = J0 + jj;
-            if (!((J <= I) && (J < T))) continue;
-            bool offdiag = I > J;
             int j = 16 * J + lr;
-            double wgt = offdiag ? 2.0 : 1.0;
+            double xj[3], Kv[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Kv[q] = Kp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int i = 16 * I + lg + 4 * q;
                 bool ok = (i < m) && (j < m);
-                double Mij = ok ? Mv[jj][q] : 0.0;
+                double Mij = ok ? acc[jj][q] : 0.0;
                 if constexpr (DIST == 0 && KERN == 0) {
-                    double kv = offdiag ? Kv[jj][q] : KernFn<0, 0>::value(kp, xi[q], xjv[jj]);
-                    double g = Mij * kv;
-                    gc_tr += (i == j) ? Mij : 0.0;
-                    gc_sv += wgt * g;
+                    double g = Mij * Kv[q];
+                    gc_sv += 2.0 * g;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
-                        double delta = xjv[jj][d] - xi[q][d];
+                        double delta = xj[d] - xi[q][d];
                         double gd = g * delta;
-                        colsum[jj][d] += gd;
-                        rowsum[q][d] -= offdiag ? gd : 0.0;
-                        gc_l[d] += wgt * gd * delta;
+                        colsum[d] += gd;
+                        rowsum[q][d] -= gd;
+                        gc_l[d] += 2.0 * gd * delta;
                     }
                 } else {
                     if (ok) {
                         double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
-                        double k = KernFn<DIST, KERN>::pair(kp, xi[q], xjv[jj], false, 0.0, dkdxi, dkdxj, dkdl);
-                        if (i != j) {
+                        double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
 #pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                colsum[jj][d] += Mij * dkdxj[d];
-                                if (offdiag) rowsum[q][d] += Mij * dkdxi[d];
-                            }
-                        } else {
-                            gc_tr += Mij;
+                        for (int d = 0; d < 3; ++d) {
+                            colsum[d] += Mij * dkdxj[d];
+                            rowsum[q][d] += Mij * dkdxi[d];
                         }
-                        gc_sv += wgt * Mij * k;
+                        gc_sv += 2.0 * Mij * k;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) gc_l[d] += wgt * Mij * dkdl[d];
+                        for (int d = 0; d < 3; ++d) gc_l[d] += 2.0 * Mij * dkdl[d];
                     }
                 }
             }
         }
+        // column sums of tile column jj over this wave's 16 rows (zero for a wave without that tile)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double v = colsum[d];
+            if constexpr (DIST == 0 && KERN == 0) v *= fx[d];
+            v += shfl_xor_d(v, 16);
+            v += shfl_xor_d(v, 32);
+            csum[jj][d] = v;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (lg == 0) red[wave][16 * jj + lr][d] = csum[jj][d];
+    // row sums of this wave's 16 rows over the block's 64 columns -> rowpart[row][JB]
+    if (active) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double rs[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 rs[d] = row16_sum(rowsum[q][d]);
-                if constexpr (DIST == 0 && KERN == 0) rs[d] *= -2.0 / (kp.ls[d] * kp.ls[d]);
+                if constexpr (DIST == 0 && KERN == 0) rs[d] *= fx[d];
             }
             if (lr < 3) {
                 double v = (lr == 0) ? rs[0] : ((lr == 1) ? rs[1] : rs[2]);
-                pl.rowpart[((roff + 16 * I + lg + 4 * q) * MAX_TB + JB) * XPAD + lr] = v;
+                pl.rowpart[((roff + 16 * I + lg + 4 * q) * tbs + JB) * XPAD + lr] = v;
             }
         }
     }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            double v = colsum[jj][d];
-            if constexpr (DIST == 0 && KERN == 0) v *= -2.0 / (kp.ls[d] * kp.ls[d]);
-            v += shfl_xor_d(v, 16);
-            v += shfl_xor_d(v, 32);
-            if (lg == 0) red[wave][16 * jj + lr][d] = v;
-        }
     if constexpr (DIST == 0 && KERN == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) gc_l[d] *= 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]);
+        for (int d = 0; d < 3; ++d) gc_l[d] *= fl[d];
     }
     double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
+    if (want_gc) {
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
-        for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+        for (int t = 0; t < 5; ++t)
+            for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+    }
     if (lane == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
     }
     __syncthreads();
     {
+        // column partial of this block pair: colpart[column j of block JB][IB]
         int jc = tid >> 2, d = tid & 3;
         int j = 64 * JB + jc;
         if (j < mp) {
             double v = 0.0;
             if (d < 3) v = red[0][jc][d] + red[1][jc][d] + red[2][jc][d] + red[3][jc][d];
-            pl.gXu[(roff + j) * XPAD + d] = v;
+            pl.colpart[((roff + j) * tbs + IB) * XPAD + d] = v;
         }
     }
     if (tid < GC_SLOTS) {
         double v = 0.0;
         if (tid < 5) v = gcred[0][tid] + gcred[1][tid] + gcred[2][tid] + gcred[3][tid];
-        pl.gcpart[((size_t)u * ut.max_T + JB) * GC_SLOTS + tid] = v;
+        int pidx = JB * TB - (JB * (JB - 1)) / 2 + (IB - JB);       // block pair index within the unit
+        pl.gcpart[((size_t)u * (TBm * (TBm + 1) / 2) + pidx) * GC_SLOTS + tid] = v;
     }
 }
 
-// gXu[row] += sum_{JB <= IB(row)} rowpart[row][JB]   (fixed order)
+// gXu[row] = sum_{IB >= B} colpart[row][IB] + sum_{JB <= B} rowpart[row][JB],  B = the row's 64-point block
+// (fixed order -> bit-reproducible)
 __global__ void k_gx_finalize(UnitTab ut, Pools pl, int total_rows) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int row = idx >> 2, d = idx & 3;
     if (row >= total_rows || d == 3) return;
     int u = ut.row_unit[row];
     int local = row - ut.row_off[u];
-    int IB = local >> 6;
-    double v = pl.gXu[(size_t)row * XPAD + d];
-    const double *rp = pl.rowpart + (size_t)row * MAX_TB * XPAD + d;
-    for (int JB = 0; JB <= IB; ++JB) v += rp[JB * XPAD];
+    int B = local >> 6;
+    int TB = ((pad16(ut.m[u]) >> 4) + 3) >> 2;
+    int tbs = (ut.max_T + 3) >> 2;
+    const double *cp = pl.colpart + (size_t)row * tbs * XPAD + d;
+    const double *rp = pl.rowpart + (size_t)row * tbs * XPAD + d;
+    double v = 0.0;
+    for (int IB = B; IB < TB; ++IB) v += cp[IB * XPAD];
+    for (int JB = 0; JB <= B; ++JB) v += rp[JB * XPAD];
     pl.gXu[(size_t)row * XPAD + d] = v;
 }
 
@@ -1723,10 +1740,11 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
                 acc[0] += w * ll;
                 if (want_gc) {
                     int T = pad16(m) >> 4;
-                    int nJ = (T + 3) >> 2;   // k_gred writes one partial per 64-column block
+                    int TB = (T + 3) >> 2, TBm = (ut.max_T + 3) >> 2;
+                    int nP = TB * (TB + 1) / 2;   // k_mgrad writes one partial per 64x64 block pair
                     double g[5] = {0, 0, 0, 0, 0};
-                    for (int J = 0; J < nJ; ++J) {
-                        const double *gp = pl.gcpart + ((size_t)u * ut.max_T + J) * GC_SLOTS;
+                    for (int P = 0; P < nP; ++P) {
+                        const double *gp = pl.gcpart + ((size_t)u * (TBm * (TBm + 1) / 2) + P) * GC_SLOTS;
                         for (int t = 0; t < 5; ++t) g[t] += gp[t];
                     }
                     acc[1] += w * 0.5 * g[0];             // d/d nv   : 1/2 tr(M)
@@ -1844,10 +1862,9 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     (void)total_rows;
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     int TBm = (ut.max_T + 3) / 4;
-    hipLaunchKernelGGL(k_mtile, dim3(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2)), dim3(256), 0, s, ut, p, kp);
-    dim3 gridr(xcd_grid(ut.n_ids, TBm));
-    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_gred<0, 0>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
-    else hipLaunchKernelGGL((k_gred<1, 1>), gridr, dim3(256), 0, s, ut, p, kp, want_gc);
+    dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
+    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_mgrad<0, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    else hipLaunchKernelGGL((k_mgrad<1, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
 }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,

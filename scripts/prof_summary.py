@@ -13,7 +13,7 @@ def find(sub, pat):
 
 
 def short(name):
-    for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
+    for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
               "k_gather_x", "k_gather_y"):
         if k in name:
             return k

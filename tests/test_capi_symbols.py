@@ -42,7 +42,7 @@ def test_code_object_targets_gfx950_with_f64_mfma():
     """The shipped .so carries a gfx950 code object (not a CPU stand-in)."""
     blob = open(build.LIB, "rb").read()
     assert b"gfx950" in blob
-    assert b"k_potrf" in blob and b"k_mtile" in blob and b"k_gred" in blob
+    assert b"k_potrf" in blob and b"k_mgrad" in blob and b"k_potrf_reg" in blob
 
 
 def test_partition_units_is_lpt_and_total():
