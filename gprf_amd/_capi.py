@@ -33,6 +33,8 @@ SIGNATURES = {
     "gprf_set_neighbors": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_nearest_center": (ctypes.c_int, [_i32, _i32, _dp, _i32, _dp, _i32p]),
     "gprf_set_block_assignment": (ctypes.c_int, [_vp, _i32, _i32p]),
+    "gprf_set_centers": (ctypes.c_int, [_vp, _i32, _dp]),
+    "gprf_assign_blocks": (ctypes.c_int, [_vp, _dp, _i32p, _i32p]),
     "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
     "gprf_partition_units": (ctypes.c_int, [_i32, _i32p, _i32, _i32, _i32p]),
     "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
@@ -183,6 +185,22 @@ class Context(object):
         assert block_of.shape == (self.n,)
         self._check(self.lib.gprf_set_block_assignment(self.h, int(n_blocks), block_of.ctypes.data_as(_i32p)),
                     "gprf_set_block_assignment")
+
+    def set_centers(self, centers):
+        centers = np.ascontiguousarray(centers, dtype=np.float64)
+        assert centers.ndim == 2 and centers.shape[1] == self.dx
+        self._check(self.lib.gprf_set_centers(self.h, centers.shape[0], dptr(centers)), "gprf_set_centers")
+
+    def assign_blocks(self, X):
+        """Device re-blocking: -> (changed, block_of or None).  When ``changed`` the context has already installed
+        the new partition."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.shape == (self.n, self.dx)
+        changed = ctypes.c_int32(0)
+        out = np.empty(self.n, dtype=np.int32)
+        self._check(self.lib.gprf_assign_blocks(self.h, dptr(X), ctypes.byref(changed), out.ctypes.data_as(_i32p)),
+                    "gprf_assign_blocks")
+        return (True, out) if changed.value else (False, None)
 
     def set_neighbors(self, pairs):
         pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))

@@ -95,6 +95,12 @@ struct gprf_ctx {
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
     DevBuf<int32_t> d_info;
+    // device re-blocking (gprf_set_centers / gprf_assign_blocks)
+    DevBuf<double> d_cs, d_c2;            // centres as structure of arrays [dx][nc] and their squared norms
+    DevBuf<int32_t> d_assign, d_changed;  // current block of every point; "somebody moved" flag
+    PinBuf<int32_t> h_assign, h_changed;
+    int n_centers = 0;
+    bool assign_valid = false;            // d_assign holds the partition the unit tables were built from
     DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
@@ -530,6 +536,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
+    c->d_cs.release(); c->d_c2.release(); c->d_assign.release(); c->d_changed.release(); c->h_assign.release(); c->h_changed.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
@@ -577,6 +584,7 @@ int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, con
         if (block_ptr[b + 1] < block_ptr[b]) return fail(c, GPRF_ERR_ARG, "block_ptr must be non-decreasing");
     int64_t tot = block_ptr[n_blocks];
     if (tot > 0 && !point_idx) return GPRF_ERR_ARG;
+    c->assign_valid = false;     // (gprf_assign_blocks sets it again after installing its own partition)
     for (int64_t k = 0; k < tot; ++k)
         if (point_idx[k] < 0 || point_idx[k] >= c->n) return fail(c, GPRF_ERR_ARG, "point index out of range");
     if (n_blocks != c->n_blocks) {
@@ -600,6 +608,7 @@ int gprf_nearest_center(int32_t n, int32_t dx, const double *X, int32_t nc, cons
     // centres as structure-of-arrays so that the radicand loop vectorises
     std::vector<double> c2(nc), cs((size_t)dx * nc);
     for (int k = 0; k < nc; ++k) {
+#pragma clang fp contract(off)
         double s = 0.0;
         for (int d = 0; d < dx; ++d) {
             double v = centers[(size_t)k * dx + d];
@@ -609,6 +618,7 @@ int gprf_nearest_center(int32_t n, int32_t dx, const double *X, int32_t nc, cons
         c2[k] = s;
     }
     auto work = [&](int p0, int p1) {
+#pragma clang fp contract(off)        // bit-for-bit the arithmetic of the device kernel k_assign
         std::vector<double> r(nc);
         for (int p = p0; p < p1; ++p) {
             const double *x = X + (size_t)p * dx;
@@ -661,6 +671,61 @@ int gprf_set_block_assignment(gprf_ctx *c, int32_t n_blocks, const int32_t *bloc
     std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
     for (int p = 0; p < c->n; ++p) pts[cur[block_of[p]]++] = p;
     return gprf_set_blocks(c, n_blocks, ptr.data(), pts.data());
+}
+
+int gprf_set_centers(gprf_ctx *c, int32_t nc, const double *centers) {
+    if (!c || nc < 1 || !centers) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int dx = c->dx;
+    std::vector<double> c2(nc), cs((size_t)dx * nc);
+    for (int k = 0; k < nc; ++k) {
+#pragma clang fp contract(off)
+        double s = 0.0;
+        for (int d = 0; d < dx; ++d) {
+            double v = centers[(size_t)k * dx + d];
+            cs[(size_t)d * nc + k] = v;
+            s += v * v;
+        }
+        c2[k] = s;
+    }
+    HIP_TRY(c, c->d_cs.reserve(cs.size() + 1));
+    HIP_TRY(c, c->d_c2.reserve(c2.size() + 1));
+    HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1));
+    HIP_TRY(c, c->d_changed.reserve(1));
+    HIP_TRY(c, c->h_assign.reserve((size_t)c->n + 1));
+    HIP_TRY(c, c->h_changed.reserve(1));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_cs.p, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_c2.p, c2.data(), c2.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t)));   // -1: everybody "moves" first time
+    c->n_centers = nc;
+    c->assign_valid = false;
+    return GPRF_OK;
+}
+
+int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *block_of_out) {
+    if (!c || !X || !changed) return GPRF_ERR_ARG;
+    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    size_t nx = (size_t)c->n * c->dx;
+    if (!c->assign_valid) HIP_TRY(c, hipMemsetAsync(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_changed.p, 0, sizeof(int32_t), s));
+    memcpy(c->h_X.p, X, nx * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_assign(c->d_X.p, c->n, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, c->d_assign.p, c->d_changed.p, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_changed.p, c->d_changed.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *changed = c->h_changed.p[0] ? 1 : 0;
+    if (!*changed) return GPRF_OK;
+    // somebody moved: bring the partition back and rebuild the unit tables from it, like a host re-blocking
+    HIP_TRY(c, hipMemcpy(c->h_assign.p, c->d_assign.p, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int rc = gprf_set_block_assignment(c, c->n_centers, c->h_assign.p);
+    if (rc != GPRF_OK) { c->assign_valid = false; return rc; }
+    c->assign_valid = true;
+    if (block_of_out) memcpy(block_of_out, c->h_assign.p, (size_t)c->n * sizeof(int32_t));
+    return GPRF_OK;
 }
 
 int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {

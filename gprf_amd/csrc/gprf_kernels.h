@@ -72,5 +72,7 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s);
+void launch_assign(const double *X, int n, int dx, const double *cs, const double *c2, int nc, int32_t *block_of,
+                   int32_t *changed, hipStream_t s);
 
 }  // namespace gprf

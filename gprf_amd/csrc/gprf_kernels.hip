@@ -1784,6 +1784,53 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // ------------------------------------------------------------------------------------------------
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
 
+// ------------------------------------------------------------------------------------------------
+// k_assign: nearest cluster centre of every point (the re-blocking the reference's drivers do before each
+// evaluation, block_clustering.py:4-5,15-17 via gprf.py:171-172), one thread per point, the centres (structure of
+// arrays + squared norms) read wave-uniformly.  Same arithmetic as the host helper gprf_nearest_center — radicand
+// x2 - 2 x.c + c2 accumulated in the same order with no FMA contraction, a negative radicand (NaN distance) wins
+// first, otherwise the first minimum — so the two agree bit for bit.  A point that changes block raises *changed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, int n, int dx, const double *__restrict__ cs,
+                                                const double *__restrict__ c2, int nc, int32_t *__restrict__ block_of,
+                                                int32_t *__restrict__ changed) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double x[8], x2 = 0.0;
+    for (int d = 0; d < dx; ++d) {
+        x[d] = X[(size_t)p * dx + d];
+        x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
+    }
+    int best = 0;
+    double bestv = 0.0;
+    bool best_nan = false;
+    for (int k = 0; k < nc && !best_nan; ++k) {
+        double r = 0.0;
+        for (int d = 0; d < dx; ++d) r = __dadd_rn(r, __dmul_rn(x[d], cs[(size_t)d * nc + k]));
+        double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2[k]);
+        if (k == 0) {
+            bestv = v;
+            best_nan = v < 0.0;
+        } else if (v < 0.0) {
+            best = k;
+            best_nan = true;
+        } else if (v < bestv) {
+            best = k;
+            bestv = v;
+        }
+    }
+    if (block_of[p] != best) {
+        block_of[p] = best;
+        *changed = 1;            // benign race: every writer stores the same value
+    }
+}
+
+void launch_assign(const double *X, int n, int dx, const double *cs, const double *c2, int nc, int32_t *block_of,
+                   int32_t *changed, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, s, X, n, dx, cs, c2, nc, block_of, changed);
+}
+
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
     if (total_rows == 0) return;
     hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);

@@ -175,11 +175,17 @@ class GPRF(object):
             from .blocking import Blocker
             if isinstance(blocker, Blocker) and getattr(self.block_fn, "__name__", "") == "block_clusters" \
                     and blocker.n_blocks == self.n_blocks:
-                block_of = blocker.block_assignment_fast(new_X)
-                self._ctx.set_block_assignment(self.n_blocks, block_of)
-                self._block_of = block_of
-                self._block_idxs = None
-                self._blocks_pushed = "assignment"
+                # nearest-centre assignment on the device; the partition comes back to the host (and the unit
+                # tables are rebuilt) only when some point changed block
+                if getattr(self, "_centers_of", None) is not blocker:
+                    self._ctx.set_centers(blocker.block_centers)
+                    self._centers_of = blocker
+                Xc = np.ascontiguousarray(new_X, dtype=np.float64)
+                changed, block_of = self._ctx.assign_blocks(Xc)
+                if changed:
+                    self._block_of = block_of
+                    self._block_idxs = None
+                    self._blocks_pushed = "assignment"
                 self._jitter = None
                 self._ctx.set_unit_jitter(None)
             else:

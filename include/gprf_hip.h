@@ -77,6 +77,16 @@ int gprf_nearest_center(int32_t n, int32_t dx, const double *X, int32_t n_center
  * order inside each block, exactly like `all_idxs[blocks == i]` (block_clustering.py:21-24). */
 int gprf_set_block_assignment(gprf_ctx *ctx, int32_t n_blocks, const int32_t *block_of);
 
+/* Device re-blocking for grid Blockers (gprfopt.py re-runs block_fn = cluster_rpc(...) on every
+ * objective call through GPRF.update_X, gprf.py:169-174).  gprf_set_centers keeps the cluster centres
+ * (n_centers x dx, row-major) in the context.  gprf_assign_blocks uploads X (n x dx), assigns every point to its
+ * nearest centre ON THE DEVICE with exactly the arithmetic and tie rule of gprf_nearest_center, and compares
+ * with the partition the unit tables were built from: *changed = 0 -> nothing else happens (the common case
+ * between L-BFGS iterates); *changed = 1 -> the new partition is installed as by gprf_set_block_assignment
+ * (n_blocks = n_centers) and, if block_of_out != NULL, copied there (n int32). */
+int gprf_set_centers(gprf_ctx *ctx, int32_t n_centers, const double *centers);
+int gprf_assign_blocks(gprf_ctx *ctx, const double *X, int32_t *changed, int32_t *block_of_out);
+
 /* self.neighbors (gprf.py:112,212): n_pairs rows (i, j); each becomes one joint unit with block i's rows
  * first (gprf.py:322).  Bethe weights 1 - deg(i) for the unaries are derived here
  * (compute_neighbor_count gprf.py:152-157; llgrad gprf.py:253-254, 264, 287).  For local=False pass all

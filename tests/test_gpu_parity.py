@@ -230,6 +230,48 @@ def test_update_X_fast_reblocking_path_equals_callable_path():
     fast.close(); slow.close()
 
 
+def test_device_reblocking_matches_host_and_oracle():
+    """gprf_assign_blocks (nearest centre on the device) == gprf_nearest_center (host helper) == the oracle's
+    BlockerRef on the same points, incl. points exactly on centres, equidistant points (first minimum wins) and
+    repeated calls: `changed` is raised only when a point really changes block."""
+    from gprf_amd import Blocker, grid_centers, GPCov, _capi
+    from gprf_amd.gprf import GPRF
+    from oracle.harness_ref import BlockerRef
+    rng = np.random.RandomState(21)
+    n = 3000
+    X = rng.rand(n, 2)
+    Y = rng.randn(n, 3)
+    C = np.asarray(grid_centers(25), dtype=np.float64)
+    b, bref = Blocker(C), BlockerRef(C)
+    X[:25] = C                                        # on the centres
+    X[25] = 0.5 * (C[0] + C[1])                       # equidistant from two centres
+    X[26] = 0.25 * (C[0] + C[1] + C[5] + C[6])        # ... from four
+    g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01, neighbors=b.neighbors())
+    g._ctx.set_centers(b.block_centers)
+    changed, dev = g._ctx.assign_blocks(X)
+    assert changed                                    # first call installs
+    host = _capi.nearest_center(X, b.block_centers)
+    ref = np.empty(n, dtype=np.int64)
+    for i, idx in enumerate(bref.block_clusters(X)):
+        ref[idx] = i
+    assert np.array_equal(dev, host)
+    far = np.abs(np.sort(np.linalg.norm(X[:, None, :] - C[None], axis=2), axis=1)[:, :2] @ [1, -1]) > 1e-12
+    assert np.array_equal(dev[far], ref[far])         # away from exact ties the oracle agrees too
+    changed2, none = g._ctx.assign_blocks(X)
+    assert not changed2 and none is None              # same points: nothing moves, nothing is rebuilt
+    X3 = X.copy()
+    X3[100] = C[(dev[100] + 7) % 25]                  # one point jumps to another block
+    changed3, dev3 = g._ctx.assign_blocks(X3)
+    assert changed3 and dev3[100] == (dev[100] + 7) % 25 and np.array_equal(np.delete(dev3, 100), np.delete(dev, 100))
+    # and the evaluation after a device re-blocking equals the one after a host re-blocking
+    slow = GPRF(X, Y, lambda Z: b.block_clusters(Z), GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01,
+                neighbors=b.neighbors())
+    g.update_X(X3); slow.update_X(X3)
+    a, c = g.llgrad(grad_X=True), slow.llgrad(grad_X=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1])
+    g.close(); slow.close()
+
+
 @pytest.mark.parametrize("dx,dy,sizes", [(1, 1, [5, 17, 40]), (3, 64, [33, 64, 16, 1, 90]), (2, 13, [100, 3, 129, 31]),
                                          (3, 7, [200, 150]), (2, 50, [257, 255])])
 def test_random_shapes_against_oracle(dx, dy, sizes):
