@@ -1857,8 +1857,19 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0) return;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
     int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
-    const char *rg = getenv("GPRF_POTRF_REG");      // A/B switch while the register-resident kernel is tuned
-    int reg_maxT = (rg && rg[0] == '0') ? 0 : POTRF_REG_MAXT;
+    // The register-resident kernel holds a whole CU per unit (one wave per SIMD): it wins on latency while the
+    // launch is a few rounds of workgroups deep (C3: 442 units, 124 vs 145 us), the 2-workgroups-per-CU generic
+    // kernel wins on throughput beyond that (C4 on one GPU: 4033 units, 857 vs 914 us).
+    // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const char *rg = getenv("GPRF_POTRF_REG");
+    bool use_reg = (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : ut.n_ids <= 4 * n_cus;
+    int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
