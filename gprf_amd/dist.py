@@ -52,6 +52,18 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def allreduce_sum_async_(t, group=None):
+    """The same collective, asynchronously: returns the work handle (``None`` when there is nothing to reduce).
+    ``handle.wait()`` makes the CURRENT stream wait for the result, it does not block the host: consecutive,
+    independent evaluations keep the compute stream busy while the previous partials are still on the wire."""
+    import os
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1"):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def agree_first_bad(bad, group=None, device=None):
     """All ranks learn the lowest failing unit id (or -1): MIN over ids with -1 mapped to +inf."""
     import torch
@@ -82,6 +94,7 @@ class DeviceEvaluator(object):
         self.stream = torch.cuda.Stream(device=dev)
         self.d_X = torch.empty(self.n * self.dx, dtype=torch.float64, device=dev)
         self.d_out = torch.empty(1 + self.n * self.dx + self.ncov, dtype=torch.float64, device=dev)
+        self._work = None              # the all-reduce still in flight on d_out, if any
 
     def set_X(self, X):
         with self.torch.cuda.stream(self.stream):
@@ -93,10 +106,21 @@ class DeviceEvaluator(object):
         returns immediately."""
         st = self.stream if stream is None else stream
         with self.torch.cuda.stream(st):
+            if self._work is not None:
+                self._work.wait()      # the stream (not the host) waits before d_out is overwritten
             self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream)
-            allreduce_sum_(self.d_out, self.group)
+            # asynchronous: RCCL runs on its own stream behind this evaluation's kernels; the next (independent)
+            # evaluation enqueued on `st` does not wait for it
+            self._work = allreduce_sum_async_(self.d_out, self.group)
+
+    def wait(self):
+        """Make the current stream wait for the pending all-reduce of this evaluator (no host block)."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
 
     def result(self, grad_X=True, grad_cov=False):
+        self.wait()
         self.torch.cuda.synchronize()
         rc, bad = self.g._ctx.eval_status()
         if rc == _capi.GPRF_NOT_PD:

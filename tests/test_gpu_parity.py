@@ -326,6 +326,39 @@ def test_two_shards_on_one_gpu_sum_to_full():
     full.close()
 
 
+def test_device_evaluator_async_allreduce_world1(monkeypatch):
+    """The RCCL leg of the multi-GPU path on one GPU: a one-rank NCCL group with the all-reduce forced on.  Several
+    evaluations are enqueued back to back (each all-reduce asynchronous behind its kernels, the next evaluation
+    not waiting for it); the result must equal the plain evaluation bit for bit (SUM over one rank)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gprf_amd import dist as gdist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("GPRF_FORCE_ALLREDUCE", "1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        z = load_golden("c1_small.npz")
+        g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY")
+        ref = g.llgrad(grad_X=True, grad_cov=True)
+        ev = gdist.DeviceEvaluator(g)
+        g._push_neighbors(g.neighbors)
+        ev.set_X(g.X)
+        for _ in range(4):
+            ev.enqueue(True, True)
+        assert ev._work is not None                       # the collective really was issued
+        out = ev.result(True, True)
+        assert out[0] == ref[0] and np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
+        g.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_permutation_invariance_and_determinism():
     """Size-independent properties: re-ordering points inside blocks leaves ll unchanged (to rounding) and
     permutes gradX; repeated evaluation is bit-identical (fixed-order reductions, no float atomics)."""
