@@ -656,11 +656,13 @@ __device__ __forceinline__ void atile_get(double (&v)[4]) {
 // tile S += sum_t a[t]^T b[t]  (four chained MFMAs), in two pieces: the caller puts the next tile's operand
 // fetch (scalar decode, address adds, LDS reads) between them, where it issues for free while the first MFMA
 // occupies the pipe — with one wave per SIMD nothing else would hide it
+// (`dep` is tied through the block without being touched: whatever the caller derives from it afterwards — the
+// next tile's slot decode — cannot be scheduled in front of this MFMA)
 template <int S>
-__device__ __forceinline__ void atile_mfma_first(const double (&a)[4], const double (&b)[4]) {
+__device__ __forceinline__ void atile_mfma_first(const double (&a)[4], const double (&b)[4], int &dep) {
     asm volatile("s_nop 1\n\t"
-                 "v_mfma_f64_16x16x4_f64 a[%2:%3], %0, %1, a[%2:%3]"
-                 :
+                 "v_mfma_f64_16x16x4_f64 a[%3:%4], %1, %2, a[%3:%4]"
+                 : "+v"(dep)
                  : "v"(a[0]), "v"(b[0]), "n"(8 * S), "n"(8 * S + 7));
 }
 template <int S>
@@ -1038,18 +1040,29 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { oa[1][t] = oa[0][t]; ob[1][t] = ob[0][t]; }
                 bool done = false;
-                static_for<0, SLOTS>([&](auto sc) {
-                    constexpr int S = SLOTS - 1 - decltype(sc)::value;
+                // in groups of 8 slots, so that the slots above s_end (small units) and below s_hi (late steps)
+                // cost one compare per group instead of one per slot
+                static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
+                    constexpr int G = (SLOTS + 7) / 8 - 1 - decltype(gc)::value;
                     int hi = s_hi, end = s_end;
-                    asm volatile("" : "+s"(hi), "+s"(end));     // (keeps the 2 * SLOTS compares from being hoisted)
-                    if (!done && S < end) {
-                        if (S < hi) {
-                            done = true;
-                        } else {
-                            atile_mfma_first<S>(oa[S & 1], ob[S & 1]);
-                            if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
-                            atile_mfma_rest<S>(oa[S & 1], ob[S & 1]);
-                        }
+                    asm volatile("" : "+s"(hi), "+s"(end));     // (keeps the compares from being hoisted)
+                    if (!done && end > 8 * G) {
+                        static_for<0, 8>([&](auto sc) {
+                            constexpr int S = 8 * G + 7 - decltype(sc)::value;
+                            if constexpr (S < SLOTS) {
+                                int hi2 = hi, end2 = end;
+                                asm volatile("" : "+s"(hi2), "+s"(end2));
+                                if (!done && S < end2) {
+                                    if (S < hi2) {
+                                        done = true;
+                                    } else {
+                                        atile_mfma_first<S>(oa[S & 1], ob[S & 1], pkv);
+                                        if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
+                                        atile_mfma_rest<S>(oa[S & 1], ob[S & 1]);
+                                    }
+                                }
+                            }
+                        });
                     }
                 });
                 atile_settle();      // before anything (the next step's dump) reads the tiles
