@@ -704,11 +704,6 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
 // Global traffic is one read of K's upper triangle and one write of U; the per-step chain is
 // substitution + factor with no memory latency in it.
 // ------------------------------------------------------------------------------------------------
-// The accumulator tiles are register-indexed by the SLOT number, which is a run-time value in the step loops:
-// a switch (one jump table) selects the asm stub with that tile's register numbers.
-#define GPRF_CASES32(M)                                                                                     \
-    M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
-    M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
 template <int RW, int SLOTS>
 __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
@@ -947,23 +942,29 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         if (mine) {
             // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
 #ifndef GPRF_ABL_NODUMP
-#pragma unroll 1
-            for (int sl = s_lo; sl < s_hi; ++sl) {
-                int pks = __builtin_amdgcn_readlane(pkv, sl);
-                double tv[4];
-#define GPRF_CASE(S)                                   \
-    case S:                                            \
-        if constexpr (S < SLOTS) atile_get<S>(tv);     \
-        break;
-                switch (sl) {
-                    GPRF_CASES32(GPRF_CASE)
-                    default: break;
-                }
-#undef GPRF_CASE
-                // stored as held (negated); the substitution's load negates
+            // (static walk in groups of 8 slots, like the trailing chain: the slot number must be a compile-time
+            // constant for the register numbers; a group costs one compare when none of its slots is in range)
+            static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
+                constexpr int G = decltype(gc)::value;
+                int lo = s_lo, hi = s_hi;
+                asm volatile("" : "+s"(lo), "+s"(hi));
+                if (hi > 8 * G && lo < 8 * G + 8) {
+                    static_for<0, 8>([&](auto sc) {
+                        constexpr int S = 8 * G + decltype(sc)::value;
+                        if constexpr (S < SLOTS) {
+                            int lo2 = lo, hi2 = hi;
+                            asm volatile("" : "+s"(lo2), "+s"(hi2));
+                            if (S >= lo2 && S < hi2) {
+                                int pks = PK(S);
+                                double tv[4];
+                                atile_get<S>(tv);     // stored as held (negated); the substitution's load negates
 #pragma unroll
-                for (int q = 0; q < 4; ++q) P[lb + (4 * q) * ldp + 16 * (pks & 31)] = tv[q];
-            }
+                                for (int q = 0; q < 4; ++q) P[lb + (4 * q) * ldp + 16 * (pks & 31)] = tv[q];
+                            }
+                        }
+                    });
+                }
+            });
 #endif
             __builtin_amdgcn_wave_barrier();
             GPRF_STAMP2(0)
