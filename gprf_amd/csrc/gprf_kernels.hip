@@ -395,7 +395,7 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr_in, double 
 template <int NWAVES>
 __device__ __forceinline__ void potrf_epilogue(const double *U, double *V, double *stage, const double *dvals,
                                                double *lred, int mp, int T, int u, const Pools &pl) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     for (int grp = wave; 4 * grp < T; grp += NWAVES) {
         int jt = 4 * grp + lg;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     __shared__ double lred[POTRF_WAVES];
     int u = ut.ids[blockIdx.x];
     int m = ut.m[u];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     if (m == 0) {
         if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
     bool is_y = bx >= ut.max_T;
     int cb = is_y ? (bx - ut.max_T) : bx;
     if (!is_y && cb >= T) return;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     size_t roff = ut.row_off[u];
     if (T == 0) {
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     int tid = threadIdx.x;
-    int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     bool is_y = part_ == nI;
     int cb = is_y ? wave : (part_ * 4 + wave);
@@ -1292,6 +1292,19 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     };
     fetch(rmin);
     double zz = 0.0;
+#ifdef GPRF_PROFILE
+    // GPRF_SOLVE_STAMPS build: wave 0 of the Y workgroup: cycles in [stage | barrier | fetch | solve tile | updates]
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    bool stamp = is_y && wave == 0;
+#define GPRF_SST(k)                                                       \
+    if (stamp) {                                                          \
+        unsigned long long tn = __builtin_amdgcn_s_memtime();             \
+        tacc[k] += tn - tprev;                                            \
+        tprev = tn;                                                       \
+    }
+#else
+#define GPRF_SST(k)
+#endif
 #pragma unroll
     for (int r = 0; r < MAXT; ++r) {
         if (r >= rmin && r < T) {                 // uniform over the workgroup
@@ -1305,8 +1318,11 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
                 }
             }
             Vl[r & 1][tid] = prev;
+            GPRF_SST(0)
             lds_barrier();                        // LDS only: no wait for the W / Z stores of the step before
+            GPRF_SST(1)
             if (r + 1 < T) fetch(r + 1);
+            GPRF_SST(2)
             if (live && r >= r0) {
                 const double *vl = Vl[r & 1] + lg * 16 + lr;
                 d4 w = {0.0, 0.0, 0.0, 0.0};
@@ -1324,6 +1340,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) wp[(size_t)(4 * q) * mp] = w[q];
                 }
+                GPRF_SST(3)
                 const double *pr = buf + lg * LDP + lr;
 #pragma unroll
                 for (int r2 = r + 1; r2 < MAXT; ++r2) {
@@ -1332,9 +1349,17 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
                         for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * r2], w[s], acc[r2]);
                     }
                 }
+                GPRF_SST(4)
             }
         }
     }
+#ifdef GPRF_PROFILE
+    if (stamp && lane == 0) {
+        for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+        pl.dbg[(size_t)u * 8 + 5] = (double)T;
+    }
+#endif
+#undef GPRF_SST
     if (live && is_y) {
         for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
         if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = zz;
@@ -1353,7 +1378,7 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     int mp = pad16(m), T = mp >> 4;
     int I0 = 16 * part_;
     if (I0 >= T) return;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     size_t roff = ut.row_off[u];
     const double *__restrict__ W = pl.W + ut.mat_off[u];
