@@ -1366,17 +1366,20 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     }
 }
 
-// k_at: At = Z^T W with one workgroup per 16 column tiles of the unit; wave w owns the column tiles
-// I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
-// DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
-// per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
+// k_at: At = Z^T W with one workgroup per AT_TILES column tiles of the unit; wave w owns the column tiles
+// I = I0 + w, w+4 and all four 16-row blocks of At for each (8 accumulators).  The k-loop runs DOWN from the
+// last row tile so the four waves need the same Z chunk at the same time (shared through L1): per k-tile 16 Z
+// operands are loaded once and reused for both column tiles; two register sets alternate so that the next
+// step's operands are already in flight.
+constexpr int AT_TILES = 8;    // column tiles of At per workgroup (two per wave)
+
 __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     int slot_, part_;
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES, &slot_, &part_)) return;
     int u = ut.ids[slot_];
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
-    int I0 = 16 * part_;
+    int I0 = AT_TILES * part_;
     if (I0 >= T) return;
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
@@ -1384,37 +1387,56 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     const double *__restrict__ W = pl.W + ut.mat_off[u];
     const double *__restrict__ Z = pl.Z + roff * YPAD;
     double *__restrict__ At = pl.At + roff * YPAD;
-    d4 acc[4][4];   // [owned column tile][16-row block of At]
+    constexpr int NO = AT_TILES / 4;
+    d4 acc[NO][4];   // [owned column tile][16-row block of At]
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[o][c] = d4{0.0, 0.0, 0.0, 0.0};
     int Imin = I0 + wave;
-    for (int kt = T - 1; kt >= I0; --kt) {
-        if (kt < Imin) continue;   // nothing of this wave's tiles reaches up here (keeps the waves in step)
+    if (Imin >= T) return;
+    // operands of one k step: the Z chunk (A, shared by the wave's tiles) and the W tiles (B); the next step's
+    // are in flight while this step's MFMAs run — a unit's chain of T steps is otherwise a chain of T memory
+    // round trips
+    auto fetch = [&](int kt, double (&a)[4][4], double (&b)[NO][4]) {
         const double *zp = Z + (size_t)(16 * kt + lg) * YPAD + lr;
-        double a[4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int c = 0; c < 4; ++c) a[s][c] = zp[(size_t)(4 * s) * YPAD + 16 * c];
         const double *wrow = W + (size_t)(16 * kt + lg) * mp + lr;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < NO; ++o) {
+            int I = I0 + wave + 4 * o;
+            bool on = I <= kt && I < T;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[o][s] = on ? wrow[(size_t)(4 * s) * mp + 16 * I] : 0.0;
+        }
+    };
+    auto mma = [&](int kt, const double (&a)[4][4], const double (&b)[NO][4]) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
             int I = I0 + wave + 4 * o;
             if (I <= kt && I < T) {
-                double b[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) b[s] = wrow[(size_t)(4 * s) * mp + 16 * I];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[o][c] = mfma(a[s][c], b[s], acc[o][c]);
+                    for (int c = 0; c < 4; ++c) acc[o][c] = mfma(a[s][c], b[o][s], acc[o][c]);
             }
+        }
+    };
+    double a0[4][4], b0[NO][4], a1[4][4], b1[NO][4];
+    fetch(T - 1, a0, b0);
+    for (int kt = T - 1; kt >= Imin; kt -= 2) {      // steps below Imin hold none of this wave's tiles (W is lower)
+        if (kt - 1 >= Imin) fetch(kt - 1, a1, b1);
+        mma(kt, a0, b0);
+        if (kt - 1 >= Imin) {
+            if (kt - 2 >= Imin) fetch(kt - 2, a0, b0);
+            mma(kt - 1, a1, b1);
         }
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < NO; ++o) {
         int I = I0 + wave + 4 * o;
         if (I < T) {
 #pragma unroll
@@ -1946,7 +1968,7 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
-    hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
+    hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
 }
 
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s) {
