@@ -273,7 +273,10 @@ def test_device_reblocking_matches_host_and_oracle():
 
 
 @pytest.mark.parametrize("dx,dy,sizes", [(1, 1, [5, 17, 40]), (3, 64, [33, 64, 16, 1, 90]), (2, 13, [100, 3, 129, 31]),
-                                         (3, 7, [200, 150]), (2, 50, [257, 255])])
+                                         (3, 7, [200, 150]), (2, 50, [257, 255]),
+                                         # pair units of exactly 14 / 15 / 16 tiles: the register-resident Cholesky's
+                                         # three tile-dealing regimes (wave 0 free / overflow only / a full share)
+                                         (2, 9, [112, 112, 120, 120, 128, 128, 127])])
 def test_random_shapes_against_oracle(dx, dy, sizes):
     """SE kernel with 1-3 input dimensions, 1..64 output columns (64 = the padded width), ragged block sizes incl.
     tile-boundary cases (16, 64, 255/257 -> pair of 512), chain of pairs + one long-range pair."""
