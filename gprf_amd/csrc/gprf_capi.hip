@@ -99,9 +99,10 @@ struct gprf_ctx {
     DevBuf<double> d_cs, d_c2;            // centres as structure of arrays [dx][nc] and their squared norms
     DevBuf<int32_t> d_assign, d_changed;  // current block of every point; "somebody moved" flag
     PinBuf<int32_t> h_assign, h_changed;
+    int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
     int n_centers = 0;
     bool assign_valid = false;            // d_assign holds the partition the unit tables were built from
-    DevBuf<double> d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
+    DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_info;
 
@@ -164,7 +165,7 @@ UnitTab make_tab(gprf_ctx *c) {
 
 Pools make_pools(gprf_ctx *c) {
     Pools p;
-    p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
+    p.K = c->d_K.p; p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
     p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
     return p;
@@ -314,6 +315,7 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
     HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1));
     HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1));
+    HIP_TRY(c, c->d_K.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
@@ -533,7 +535,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_m.release(); c->d_rowoff.release();
     c->d_upt.release(); c->d_slot_row.release(); c->d_info.release(); c->d_matoff.release();
     c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
-    c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
+    c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
     c->d_cs.release(); c->d_c2.release(); c->d_assign.release(); c->d_changed.release(); c->h_assign.release(); c->h_changed.release();
@@ -866,6 +868,7 @@ int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
     size_t nx = (size_t)c->n * c->dx;
     memcpy(c->h_X.p, X, nx * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->last_stop_after = stop_after;
     rc = enqueue_eval(c, c->d_X.p, 1, 1, c->d_out.p, c->stream, stop_after);
     if (rc != GPRF_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -890,7 +893,8 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
     const double *src = nullptr;
     int64_t len = 0;
     switch (what) {
-        case 0: src = c->d_U.p + c->l_matoff[l]; len = mp * mp; break;
+        case 0:   // after a fill-only debug run the K pool (upper 64x64 blocks), otherwise the factor
+            src = (c->last_stop_after == 0 ? c->d_K.p : c->d_U.p) + c->l_matoff[l]; len = mp * mp; break;
         case 1: src = c->d_W.p + c->l_matoff[l]; len = mp * mp; break;
         case 2: src = c->d_Z.p + roff * YPAD; len = mp * YPAD; break;
         case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;

@@ -38,7 +38,9 @@ struct UnitTab {
 };
 
 struct Pools {
-    double *U;     // K, overwritten by its upper Cholesky factor (row-major mp x mp per unit)
+    double *K;     // kernel matrices, row-major mp x mp per unit: k_fill writes the 64x64 blocks ti <= tj only
+                   // (diagonal blocks whole); read by the Cholesky once and by k_mgrad
+    double *U;     // upper Cholesky factors (same layout; the strictly-lower part is never written)
     double *W;     // U^-T (lower triangular, row-major)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
     double *Xu;    // gathered unit coordinates, XPAD per padded row

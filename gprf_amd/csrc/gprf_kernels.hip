@@ -220,7 +220,6 @@ __global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__rest
 template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) {
     __shared__ double xr[64 * XPAD];
-    __shared__ double tb[64 * 65];
     int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m);
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
     double xj[XPAD];
     for (int d = 0; d < XPAD; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XPAD + d] : 0.0;
     __syncthreads();
-    double *U = pl.U + ut.mat_off[u];
+    double *U = pl.K + ut.mat_off[u];     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
     double diag_add = kp.nv + ut.jitter[u];
     int rbase = t >> 6;
 #pragma unroll 4
@@ -259,18 +258,6 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
             }
             U[(size_t)row * mp + col] = v;
         }
-        tb[rl * 65 + cl] = v;
-    }
-    if (ti == tj) return;
-    __syncthreads();
-    // transposed tile: element [c0 + rr][r0 + l] = tile[l][rr]
-    int l = t & 63;
-    int tcol = r0 + l;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        int rr = rbase + 4 * q;
-        int trow = c0 + rr;
-        if (trow < mp && tcol < mp) U[(size_t)trow * mp + tcol] = tb[l * 65 + rr];
     }
 }
 
@@ -466,6 +453,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     double *Tt = rdt + 16;                // [16][17]  look-ahead tile, row-major
     double *dvals = Tt + 16 * 17;         // [mp]      diagonal of U
     double *U = pl.U + ut.mat_off[u];
+    const double *Kp = pl.K + ut.mat_off[u];   // every tile is first read from the K pool (all of them in step 0)
     double *V = pl.V + (size_t)ut.row_off[u] * 16;
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
@@ -488,7 +476,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     if (wave == 0) {
         double s[16], dk, rdk;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = U[(size_t)i * mp + lr];
+        for (int i = 0; i < 16; ++i) s[i] = Kp[(size_t)i * mp + lr];
         int bad = diag_factor16(s, lr, &dk, &rdk);
         publish(s, dk, rdk, 0, bad);
     }
@@ -513,13 +501,15 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         if (ntr == 0) break;
         // ---- row panel by forward substitution: 64 columns per wave task, one column per lane ----
         int ncol = 16 * ntr;
+        const double *Csrc = (j == 0) ? Kp : U;   // the trailing matrix: K itself in step 0, U's pool afterwards
         for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
             int col = 16 * (j + 1) + c0 + lane;
             if (c0 + lane < ncol) {
                 double x[16];
                 double *Cc = U + (size_t)(16 * j) * mp + col;
+                const double *Cr = Csrc + (size_t)(16 * j) * mp + col;
 #pragma unroll
-                for (int a = 0; a < 16; ++a) x[a] = Cc[(size_t)a * mp];
+                for (int a = 0; a < 16; ++a) x[a] = Cr[(size_t)a * mp];
                 // U_jj one column per lane (in each row of 16 lanes): U[c][a] reaches the FMA by DPP broadcast from
                 // lane a — 16 LDS reads up front instead of one per FMA
                 double uc[16], rdl = rdt[lr];
@@ -546,7 +536,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         if (wave == 0) {
             // look-ahead: tile (j+1, j+1) -> LDS (row-major) -> one column per lane -> factor
             int i = j + 1;
-            const double *Cii = U + (size_t)(16 * i + lg) * mp + 16 * i + lr;
+            const double *Cii = Csrc + (size_t)(16 * i + lg) * mp + 16 * i + lr;
             d4 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = Cii[(size_t)(4 * q) * mp];
@@ -575,21 +565,23 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
                     int k = (i == j + 1) ? i + 1 : i;
                     if (k >= T) continue;
                     double *Cik = U + (size_t)(16 * i + lg) * mp + 16 * k + lr;
+                    const double *Rik = Csrc + (size_t)(16 * i + lg) * mp + 16 * k + lr;   // read side
                     const double *Pk = P + lg * ldp + 16 * k + lr;
                     d4 cur;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cur[q] = Cik[(size_t)(4 * q) * mp];
+                    for (int q = 0; q < 4; ++q) cur[q] = Rik[(size_t)(4 * q) * mp];
                     for (; k < T; ++k) {
                         d4 nxt = {0.0, 0.0, 0.0, 0.0};
                         if (k + 1 < T) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) nxt[q] = Cik[(size_t)(4 * q) * mp + 16];
+                            for (int q = 0; q < 4; ++q) nxt[q] = Rik[(size_t)(4 * q) * mp + 16];
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s) cur = mfma(a[s], Pk[(4 * s) * ldp], cur);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = cur[q];
                         Cik += 16;
+                        Rik += 16;
                         Pk += 16;
                         cur = nxt;
                     }
@@ -733,6 +725,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     double *dvals = rdt + 16;             // [16 T]    diagonal of U
     double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
     double *U = pl.U + ut.mat_off[u];
+    const double *Kp = pl.K + ut.mat_off[u];   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
     double *V = pl.V + (size_t)ut.row_off[u] * 16;
     if (threadIdx.x == 0) s_fail = 0;
     unsigned glane = (unsigned)(lg * mp + lr);
@@ -786,7 +779,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     for (int i = wave; i < T; i += RW) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double *Cs = U + (size_t)(16 * i + 4 * q) * mp + 16 * i;
+            const double *Cs = Kp + (size_t)(16 * i + 4 * q) * mp + 16 * i;
             Dt[i * 256 + 64 * q + dlane] = Cs[glane];
         }
     }
@@ -842,7 +835,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
                 int pc = pks < 0 ? 0 : pks;
     #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double *Cs = U + (size_t)(16 * (pc >> 5) + 4 * q) * mp + 16 * (pc & 31);
+                    const double *Cs = Kp + (size_t)(16 * (pc >> 5) + 4 * q) * mp + 16 * (pc & 31);
                     kv[i][q] = -Cs[glane];            // the accumulators hold MINUS the trailing tile
                 }
             }
@@ -1366,6 +1359,65 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     }
 }
 
+// k_at_wide: the throughput form of k_at (many units per CU): one workgroup per 16 column tiles of the unit; wave w owns the column tiles
+// I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
+// DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
+// per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
+__global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
+    int slot_, part_;
+    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    int u = ut.ids[slot_];
+    int m = ut.m[u];
+    int mp = pad16(m), T = mp >> 4;
+    int I0 = 16 * part_;
+    if (I0 >= T) return;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
+    int lr = lane & 15, lg = lane >> 4;
+    size_t roff = ut.row_off[u];
+    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    const double *__restrict__ Z = pl.Z + roff * YPAD;
+    double *__restrict__ At = pl.At + roff * YPAD;
+    d4 acc[4][4];   // [owned column tile][16-row block of At]
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = d4{0.0, 0.0, 0.0, 0.0};
+    int Imin = I0 + wave;
+    for (int kt = T - 1; kt >= I0; --kt) {
+        if (kt < Imin) continue;   // nothing of this wave's tiles reaches up here (keeps the waves in step)
+        const double *zp = Z + (size_t)(16 * kt + lg) * YPAD + lr;
+        double a[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[s][c] = zp[(size_t)(4 * s) * YPAD + 16 * c];
+        const double *wrow = W + (size_t)(16 * kt + lg) * mp + lr;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            int I = I0 + wave + 4 * o;
+            if (I <= kt && I < T) {
+                double b[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = wrow[(size_t)(4 * s) * mp + 16 * I];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[o][c] = mfma(a[s][c], b[s], acc[o][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        int I = I0 + wave + 4 * o;
+        if (I < T) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[o][c][q];
+        }
+    }
+}
+
 // k_at: At = Z^T W with one workgroup per AT_TILES column tiles of the unit; wave w owns the column tiles
 // I = I0 + w, w+4 and all four 16-row blocks of At for each (8 accumulators).  The k-loop runs DOWN from the
 // last row tile so the four waves need the same Z chunk at the same time (shared through L1): per k-tile 16 Z
@@ -1584,7 +1636,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     __syncthreads();                                   // the staging buffer is reused for the reductions
     double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
     double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
-    const double *__restrict__ Kp = pl.U + ut.mat_off[u];
+    const double *__restrict__ Kp = pl.K + ut.mat_off[u];
     const double *__restrict__ Xu = pl.Xu + roff * XPAD;
     const int tbs = TBm;                               // stride of the per-block partials
     double rowsum[4][3], xi[4][3];
@@ -1650,7 +1702,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             }
         }
     }
-    // strictly-lower tiles: k read back from the K/U pool (the Cholesky only overwrites the upper triangle);
+    // strictly-lower tiles: k read back from the K pool, which holds the 64x64 blocks JB <= IB only: transposed
+    // access for an off-diagonal block pair (the four q-loads of a lane cover one 128-byte line);
     // column sums for the points of J, row sums for the points of I, everything counted twice in the theta sums
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -1663,7 +1716,9 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
 #pragma unroll
             for (int d = 0; d < 3; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Kv[q] = Kp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr];
+            for (int q = 0; q < 4; ++q)
+                Kv[q] = diagblk ? Kp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr]      // diagonal blocks are whole
+                                : Kp[(size_t)(16 * J + lr) * mp + 16 * I + lg + 4 * q];     // K(i,j) = K(j,i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int i = 16 * I + lg + 4 * q;
@@ -1843,6 +1898,17 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// compute units of the current device (kernel variants are picked by how many workgroup rounds a launch is deep)
+static int device_cus() {
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return n_cus;
+}
+
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
 
 // ------------------------------------------------------------------------------------------------
@@ -1922,12 +1988,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     // launch is a few rounds of workgroups deep (C3: 442 units, 124 vs 145 us), the 2-workgroups-per-CU generic
     // kernel wins on throughput beyond that (C4 on one GPU: 4033 units, 857 vs 914 us).
     // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
-    static int n_cus = 0;
-    if (n_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cus = device_cus();
     const char *rg = getenv("GPRF_POTRF_REG");
     bool use_reg = (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : ut.n_ids <= 4 * n_cus;
     int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
@@ -1968,7 +2029,12 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
-    hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
+    // single-unit latency matters while the launch is about one workgroup-round deep (sharded runs); beyond
+    // that the wide form's operand reuse wins (C3 on one GPU: 55 vs 58 us, C4: 324 vs 429 us)
+    if (ut.n_ids <= device_cus())
+        hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
+    else
+        hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
 }
 
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s) {

@@ -141,7 +141,9 @@ int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
 #define GPRF_N_STAGES 7
 
 /* Per-stage parity hooks (tests only): after an evaluation, copy one local unit's intermediates to the
- * host.  what: 0 K-fill/U (mp x mp, upper triangle = Cholesky factor U, K = U^T U, after potrf),
+ * host.  what: 0 the factor pool (mp x mp, upper triangle = Cholesky factor U, K = U^T U; the strictly-lower
+ * part is unspecified) — or, after a fill-only gprf_debug_run (stop_after = 0), the K pool (64x64 blocks
+ * ti <= tj, the rest unspecified),
  * 1 W = U^-T (mp x mp, lower), 2 Z = U^-T Y (mp x 64), 3 At = (K^-1 Y)^T (64 x mp),
  * 4 per-row gradient slab (mp x 4), 5 [ll_u, logdet_u, zz_u, info_u], 6 eight in-kernel cycle
  * counters of diagnostic builds, 7 / 8 the gradient reduction's per-block column / row partials
