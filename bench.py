@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--task", default="x", choices=["x", "xcov"])
     ap.add_argument("--distinct-x", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true",
+                    help="diagnostic: no HIP events between the kernels in the timed region (no roofline then)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -97,6 +99,9 @@ def cpu_baseline(sd, local_dist, seconds, grad_cov):
                       "(reference-shaped per-row derivative calls), BLAS threads=%d" % (out["rows"][1], g.n_blocks + len(g.neighbors), threads),
             "vectorised_value": out["matrix"][0],
             "vectorised_sample": "%d full evaluation(s), oracle mode=matrix" % out["matrix"][1]}
+
+
+TIMING_PERIOD = 7
 
 
 def main():
@@ -201,12 +206,22 @@ def main():
     for k in range(args.warmup):
         evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
     barrier()
+    # HIP events between the kernels cost ~3 us of stream time each (25 us per evaluation with all 8 of them):
+    # the stage durations are sampled on every TIMING_PERIOD-th evaluation of the timed region (a period coprime
+    # with the number of distinct X, so every context is sampled)
     for ev in evs:
         ev.g._ctx.set_timing(True, reset=True)
+        ev.g._ctx.set_timing(False)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
+        e = evs[k % nX]
+        sampled = (not args.no_stage_timing) and k % TIMING_PERIOD == 0
+        if sampled:
+            e.g._ctx.set_timing(True)
+        e.enqueue(True, grad_cov, stream=run_stream)
+        if sampled:
+            e.g._ctx.set_timing(False)
     barrier()
     elapsed = time.perf_counter() - t0
     for ev in evs:
@@ -217,12 +232,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if args.no_stage_timing:
+        if rank == 0:
+            print(json.dumps({"diagnostic": "no HIP events between kernels in the timed region", "value": args.steps / elapsed,
+                              "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps, "n_gpus": world}))
+        return
     # per-stage averages over the timed region (HIP events on the launch stream), this rank's shard
     used = [ev for i, ev in enumerate(evs) if i < args.steps]
     stage = {}
     cnt = 0
     for ev in used:
-        tm = ev.g._ctx.get_timing()
+        try:
+            tm = ev.g._ctx.get_timing()
+        except _capi.GprfHipError:      # a context the sampling never reached (very short runs)
+            continue
         c = tm.pop("count")
         cnt += c
         for kname, v in tm.items():
@@ -279,6 +302,8 @@ def main():
                        "distinct_X": nX, "parallelism": "units sharded over %d rank(s), 1 all-reduce/eval" % world},
             "roofline": roof,
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
+            "stage_timing": "HIP events between the kernels on every %d-th evaluation of the timed region (%d sampled)"
+                            % (TIMING_PERIOD, cnt),
         }
 
     # ---------------- secondary rates (N = 1 only): synchronous, host-inclusive, local-GP config
