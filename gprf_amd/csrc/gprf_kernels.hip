@@ -659,7 +659,8 @@ __device__ __forceinline__ void atile_mfma_first(const double (&a)[4], const dou
 }
 template <int S>
 __device__ __forceinline__ void atile_mfma_rest(const double (&a)[4], const double (&b)[4]) {
-    asm volatile("v_mfma_f64_16x16x4_f64 a[%6:%7], %0, %1, a[%6:%7]\n\t"
+    asm volatile("s_nop 1\n\t"          // (a compiler-inserted copy of an operand may sit right in front)
+                 "v_mfma_f64_16x16x4_f64 a[%6:%7], %0, %1, a[%6:%7]\n\t"
                  "v_mfma_f64_16x16x4_f64 a[%6:%7], %2, %3, a[%6:%7]\n\t"
                  "v_mfma_f64_16x16x4_f64 a[%6:%7], %4, %5, a[%6:%7]"
                  :
