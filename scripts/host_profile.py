@@ -27,3 +27,16 @@ print("eval only %.3f ms" % t(lambda: g._ctx.eval(X2, True, False)))
 def f2():
     g.update_X(X2); g.llgrad(grad_X=True)
 print("update_X+llgrad %.3f ms" % t(f2))
+# re-blocking that really changes the partition every time (a few points cross block borders)
+ts_u, ts_l = [], []
+for it in range(30):
+    X3 = X + 2e-3 * rng.randn(n, 2)
+    t0 = time.perf_counter(); g.update_X(X3); t1 = time.perf_counter(); g.llgrad(grad_X=True); t2 = time.perf_counter()
+    ts_u.append(t1 - t0); ts_l.append(t2 - t1)
+print("changing partition: update_X %.3f ms  llgrad %.3f ms" % (np.median(ts_u) * 1e3, np.median(ts_l) * 1e3))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for it in range(20):
+    X3 = X + 2e-3 * rng.randn(n, 2); g.update_X(X3); g.llgrad(grad_X=True)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
