@@ -278,11 +278,11 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01d_traffic.json")))
             key = {"potrf": "k_potrf_reg", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 roof["traffic"] = tr[key]["bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01c_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                roof["traffic_source"] = "profiles/r01d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         except Exception:
             pass
         roof["avg_launch_ms"] = stage[dom]
