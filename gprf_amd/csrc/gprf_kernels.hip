@@ -684,9 +684,9 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
 // ------------------------------------------------------------------------------------------------
 // k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
 // chip (T <= reg_maxT tiles per edge).  The trailing matrix never goes back to memory: the strictly-upper
-// tiles, enumerated row-major, are dealt cyclically to waves 1..7 (tile idx -> wave 1 + idx%7, slot idx/7)
-// and live in their MFMA accumulators, so that every row panel and every trailing update is spread over all
-// seven; the T diagonal tiles live in LDS (Dt).  Step j:
+// tiles, enumerated row-major, are dealt cyclically to the worker waves 1..3 (and, for the largest units, the
+// first few rows also to wave 0) and live in explicitly numbered AGPR tiles, so that every row panel and every
+// trailing update is spread over the workers; the T diagonal tiles live in LDS (Dt).  Step j:
 //   waves 1..7: their tiles of row j -> LDS panel -> one column per lane -> forward substitution (DPP
 //               broadcast of U_jj) -> LDS panel + global U
 //   barrier
@@ -732,33 +732,29 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     unsigned glane = (unsigned)(lg * mp + lr);
     int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
 
-    // Dealing the strictly-upper tiles (row-major index idx) to the waves: in every period of dP = 3 dm + 1
-    // consecutive tiles, workers 1..3 take dm each (positions w, w+3, ...) and wave 0 the last one.  While the
-    // three workers' 3 * SLOTS slots hold everything (T <= 14) dm = SLOTS and the period is never completed: wave
-    // 0 only factors.  Larger units shorten the period until the workers fit; wave 0 then has trailing work after
-    // its factor, as little as possible.
+    // Dealing the strictly-upper tiles (row-major index idx) to the waves.  While the three workers' 3 * SLOTS slots
+    // hold everything (T <= 14) they take the tiles cyclically (idx % 3) and wave 0 only factors.  A larger unit
+    // has ov = total - 3 SLOTS tiles too many: its FIRST 4 ov tiles are dealt to all four waves (idx % 4, wave 0
+    // taking idx % 4 == 3), the rest to the workers as before.  Wave 0's tiles then lie in the first rows: they are
+    // the first to retire, so its trailing work (which runs after its factor, on the critical path) is over after
+    // a few steps instead of staying a quarter of everything.
     static_assert(RW == 4, "three workers + the factor wave");
     const int total = T * (T - 1) / 2;
-    int dm = SLOTS;
-    if (total > 3 * SLOTS) {
-        for (dm = SLOTS / 2; dm > 1; --dm) {
-            int dP = 3 * dm + 1, x = total % dP;
-            int c = (total / dP) * dm + (x + 2) / 3;
-            if ((x + 2) / 3 > dm) c = (total / dP) * dm + dm;
-            if (c <= SLOTS) break;
-        }
-    }
-    dm = __builtin_amdgcn_readfirstlane(dm);
-    const int dP = 3 * dm + 1;
-    const bool w0busy = total > 3 * SLOTS;             // wave 0 owns tiles too
+    const int ov = total > 3 * SLOTS ? total - 3 * SLOTS : 0;
+    const int head = 4 * ov < total ? 4 * ov : total;
+    const bool w0busy = ov > 0;                        // wave 0 owns tiles too
     const bool mine = wave > 0 || w0busy;
+    const int wpos = wave == 0 ? 3 : wave - 1;         // position in the four-way deal; workers: also in the three-way
+    const int nhead = (head - wpos + 3) >> 2;          // this wave's tiles of the four-way part (head >= 3 or 0)
     // tiles of this wave among idx < r
     auto cnt = [&](int r) {
-        int q = r / dP, x = r % dP;
-        if (wave == 0) return q;
-        int c = (x - (wave - 1) + 2) / 3;
-        if (x - (wave - 1) + 2 < 0) c = 0;
-        return q * dm + (c < 0 ? 0 : (c > dm ? dm : c));
+        if (r <= head) {
+            int c = (r - wpos + 3) >> 2;
+            return c < 0 ? 0 : c;
+        }
+        if (wave == 0) return nhead;
+        int c = (r - head - wpos + 2) / 3;
+        return nhead + (r - head - wpos + 2 < 0 ? 0 : c);
     };
     // lane s: slot s -> tile, 32 * tile row + tile column, or -1 (fetched with v_readlane / a shuffle where
     // needed: 30-odd live SGPRs would crowd out the row pointers);  lane j: s_hi of step j = this wave's tiles
@@ -766,7 +762,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     int pkv = -1, shv = 0;
     {
         int sl = lane;
-        int idx = (wave == 0) ? sl * dP + dP - 1 : (sl / dm) * dP + 3 * (sl % dm) + (wave - 1);
+        int idx = sl < nhead ? 4 * sl + wpos : (wave == 0 ? total : head + 3 * (sl - nhead) + wpos);
         int i = 0, rs = 0, rl = T - 1;
         while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
         if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
