@@ -1559,6 +1559,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     bool diagblk = IB == JB;
     double dyd = (double)kp.dy;
     int nchA = (kp.dy + 15) >> 4;
+    int ks_last = ((kp.dy - 16 * (nchA - 1)) + 3) >> 2;   // k-steps of the last At chunk that hold real rows
     int nchW = T - 4 * IB;
     int nch = nchW + nchA;
 
@@ -1590,7 +1591,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
 #pragma unroll
         for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
     };
-    auto mma_chunk = [&](const double *buf, double asc) {
+    // ks = MFMA k-steps of 4 rows this chunk really has (the last At chunk: rows dy .. are zero padding)
+    auto mma_chunk = [&](const double *buf, double asc, int ks) {
         const double *rowp = buf + lg * G2_LD + lr;
         double a[4];
 #pragma unroll
@@ -1602,7 +1604,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
 #pragma unroll
                 for (int s = 0; s < 4; ++s) b[s] = rowp[(4 * s) * G2_LD + boff + 16 * jj];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[jj] = mfma(a[s], b[s], acc[jj]);
+                for (int s = 0; s < 4; ++s)
+                    if (s < ks) acc[jj] = mfma(a[s], b[s], acc[jj]);
             }
         }
     };
@@ -1617,9 +1620,9 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         // the -dy of the W part rides on the A operand (4 multiplies per chunk): the accumulators are never
         // rescaled in the middle of the chunk loop
         if (c < nchW) {
-            if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd);
+            if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd, 4);
         } else {
-            if (active) mma_chunk(buf, 1.0);
+            if (active) mma_chunk(buf, 1.0, (c == nch - 1) ? ks_last : 4);
         }
     };
     fetch0(0);
