@@ -1898,6 +1898,18 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
+// granted for (kernel slot, current device)
+static bool lds_needs_optin(int kernel_slot, size_t lds) {
+    static size_t granted[2][64] = {};
+    if (lds <= 48 * 1024) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (lds <= granted[kernel_slot][dev]) return false;
+    granted[kernel_slot][dev] = lds;
+    return true;
+}
+
 // compute units of the current device (kernel variants are picked by how many workgroup rounds a launch is deep)
 static int device_cus() {
     static int n_cus = 0;
@@ -1995,23 +2007,17 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
-        static size_t lds_set_r = 0;
-        if (lds > 48 * 1024 && lds > lds_set_r) {
+        if (lds_needs_optin(0, lds))
             (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_set_r = lds;
-        }
         hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
                            ut, p,
                            stamps, reg_maxT);
         if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
     }
     size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
+    if (lds_needs_optin(1, lds))
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, stamps, reg_maxT);
 }
 
