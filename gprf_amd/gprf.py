@@ -131,21 +131,9 @@ class GPRF(object):
     def compute_neighbors(self, threshold=1e-3):
         """gprf.py:119-150: connect blocks whose largest cross-covariance (relative to the signal
         variance) exceeds ``threshold``; 1.0 means no pairs.  One-time setup, evaluated on the host with
-        the same kernel definitions."""
-        neighbors = []
-        if threshold == 1.0:
-            self.neighbors = neighbors
-            return
-        from .hostkernels import cross_kernel_max
-        for i in range(self.n_blocks):
-            X1 = self.X[self.block_idxs[i]]
-            for j in range(i):
-                X2 = self.X[self.block_idxs[j]]
-                if len(X1) == 0 or len(X2) == 0:
-                    continue
-                if cross_kernel_max(X1, X2, self.cov) > threshold:
-                    neighbors.append((i, j))
-        self.neighbors = neighbors
+        the same kernel definitions (block pairs whose bounding boxes are already too far apart are skipped)."""
+        from .hostkernels import threshold_neighbors
+        self.neighbors = threshold_neighbors(self.X, self.block_idxs, self.cov, threshold)
 
     def compute_neighbor_count(self):
         """gprf.py:152-157"""

@@ -146,3 +146,26 @@ def test_synthetic_recipe_matches_oracle_recipe():
     assert a.neighbors == b.neighbors
     assert all(np.array_equal(u, v) for u, v in zip(a.block_idxs, b.block_idxs))
     assert a.x_prior(a.X_obs.flatten() + 0.01)[0] == b.x_prior(b.X_obs.flatten() + 0.01)[0]
+
+
+def test_threshold_neighbors_pruned_equals_exhaustive_oracle():
+    """GPRF.compute_neighbors' host routine (bounding-box pruning) returns exactly the oracle's exhaustive pair list
+    (gprf.py:119-150), in the same order, for both kernels, several thresholds, anisotropic lengthscales, empty
+    blocks and blocks that interleave (boxes overlap)."""
+    from gprf_amd import GPCov, Blocker, grid_centers
+    from gprf_amd.hostkernels import threshold_neighbors
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(4)
+    X = rng.rand(1200, 2)
+    Y = rng.randn(1200, 2)
+    b = Blocker(grid_centers(36))
+    blocks = [np.asarray(i) for i in b.block_clusters(X)]
+    blocks[7] = np.zeros(0, dtype=np.int64)                         # an empty block
+    blocks[3], blocks[20] = np.concatenate([blocks[3][::2], blocks[20][::2]]), np.concatenate([blocks[3][1::2], blocks[20][1::2]])
+    for wfn, ls, thr in (("se", [0.05, 0.08], 1e-3), ("se", [0.12, 0.03], 0.3), ("matern32", [0.04, 0.04], 1e-2),
+                         ("se", [0.05, 0.05], 1.0), ("se", [0.5, 0.5], 1e-6)):
+        got = threshold_neighbors(X, blocks, GPCov([1.3], ls, "euclidean", wfn), thr)
+        ref = GPRFRef(X, Y, None, OC([1.3], ls, "euclidean", wfn), 0.01, block_idxs=blocks, neighbors=[])
+        ref.compute_neighbors(threshold=thr)
+        assert got == [(int(i), int(j)) for (i, j) in ref.neighbors], (wfn, ls, thr)
