@@ -1,0 +1,76 @@
+"""Seismic configuration (great-circle/depth distance, Matern-3/2, principal-direction-tree blocks,
+L-BFGS-B callback of run_seismic.py) through the HIP path, against the oracle's GPRF restatement driven by the oracle's
+restatement of the same callback.  fp64; tolerances per assertion.  Parity unpinned beyond the restatement: the
+reference's catalogue file is not distributed (gprf_amd.seismic.synthetic_events is a stand-in)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=420, blocksize=60, yd=4, threshold=0.6, seed=0):
+    from gprf_amd import GPCov, seismic
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    from oracle import seismic_ref
+    Xtrue = seismic.synthetic_events(n, seed=seed)
+    # run_seismic.py's noise and signal variance; 150 km instead of its 40 km lengthscales so that a catalogue this
+    # small still has block pairs above the edge threshold
+    theta = (0.1, 1.0, 150.0, 150.0)
+    cov = GPCov([theta[1]], list(theta[2:]), "lld", "matern32")
+    Y = seismic.sample_y(Xtrue, cov, theta[0], yd, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    obs_std = 2.0
+    Xobs = Xtrue + rng.randn(n, 3) * obs_std * np.array([.01, .01, 1.0])
+    Xobs[:, 2] = np.abs(Xobs[:, 2])
+    blocks, reblock = seismic.pdtree_cluster(Xobs, blocksize=blocksize)
+    rblocks, rreblock = seismic_ref.pdtree_cluster_ref(Xobs, blocksize=blocksize)
+    g = GPRF(Xobs, Y, reblock, cov, theta[0], neighbor_threshold=threshold)
+    r = GPRFRef(Xobs, Y, rreblock, OC([theta[1]], list(theta[2:]), "lld", "matern32"), theta[0],
+                neighbor_threshold=threshold)
+    return g, r, Xobs, np.array([theta]), obs_std
+
+
+def test_partition_and_neighbours_match():
+    g, r, Xobs, C0, _ = _setup()
+    assert len(g.block_idxs) == len(r.block_idxs) >= 8
+    assert all(np.array_equal(a, b) for a, b in zip(g.block_idxs, r.block_idxs))
+    assert sorted(map(tuple, g.neighbors)) == sorted(map(tuple, r.neighbors)) and len(g.neighbors) > 0
+    g.close()
+
+
+@pytest.mark.parametrize("task", ["x", "xcov"])
+def test_objective_matches_oracle_through_the_callback(task):
+    from gprf_amd import seismic
+    from oracle import seismic_ref
+    g, r, Xobs, C0, obs_std = _setup()
+    C = C0 if task == "xcov" else None
+    o = seismic.SeismicObjective(g, Xobs, C, seismic.seismic_cov_prior, seismic.make_x_prior(Xobs, obs_std))
+    q = seismic_ref.SeismicObjectiveRef(r, Xobs, C, seismic_ref.seismic_cov_prior_ref,
+                                        seismic_ref.make_x_prior_ref(Xobs, obs_std))
+    rng = np.random.RandomState(3)
+    x = o.full0.copy()
+    for it in range(3):
+        (f, gr), (rf, rgr) = o(x), q(x.copy())
+        assert np.isclose(f, rf, rtol=1e-11)
+        assert np.max(np.abs(gr - rgr)) <= 1e-9 * np.max(np.abs(rgr))
+        # move the events (they change blocks: the tree re-routes them) and, for xcov, the log-hyperparameters
+        step = rng.randn(len(x)) * 0.02
+        step[2:o.nx:3] *= 0.05                                          # depth is in units of 100 km here
+        x = x + step
+    assert any(len(a) != len(b) for a, b in zip(g.block_idxs, seismic.pdtree_cluster(Xobs, 60)[0]))
+    assert all(np.array_equal(a, b) for a, b in zip(g.block_idxs, r.block_idxs))
+    g.close()
+
+
+def test_short_optimisation_improves_objective_and_locations():
+    """A few L-BFGS-B iterations through do_seismic_optimization: the objective falls and stays finite (no oracle)."""
+    from gprf_amd import seismic
+    g, _, Xobs, C0, obs_std = _setup()
+    xp = seismic.make_x_prior(Xobs, obs_std)
+    res, obj = seismic.do_seismic_optimization(g, Xobs, None, xp, maxsec=300, maxiter=5)
+    assert res is not None and np.isfinite(res.fun)
+    f0, _ = seismic.SeismicObjective(g, Xobs, None, x_prior=xp)(obj.full0)
+    assert res.fun < f0
+    g.close()
