@@ -319,7 +319,7 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
-    HIP_TRY(c, c->d_Xu.reserve((size_t)rows * XPAD + 1));
+    HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1));      // XPAD, or 8 for the lld record
     HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));
     HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1));
     HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1));
@@ -423,7 +423,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
     if (G == 1 || tm) {
         mark();
-        launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
+        launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, (int)c->total_rows, s);
         mark();
         launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
         mark();
@@ -449,7 +449,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
             }
             c->groups_ready = true;
         }
-        launch_gather_x(ut, pl, d_X, c->dx, (int)c->total_rows, s);
+        launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, (int)c->total_rows, s);
         HIP_TRY(c, hipEventRecord(c->gev_start, s));
         for (int g = 0; g < G; ++g) {
             UnitTab ug = ut;

@@ -43,7 +43,8 @@ struct Pools {
     double *U;     // upper Cholesky factors (same layout; the strictly-lower part is never written)
     double *W;     // U^-T (lower triangular, row-major)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
-    double *Xu;    // gathered unit coordinates, XPAD per padded row
+    double *Xu;    // gathered unit coordinates per padded row: XPAD doubles (euclidean) or the 8-double half-angle
+                   // record of the lld distance (k_gather_x)
     double *Yu;    // gathered unit outputs, YPAD per padded row (zero padded)
     double *Z;     // U^-T Yu, YPAD per padded row
     double *At;    // (K^-1 Yu)^T : per unit YPAD x mp at YPAD*row_off
@@ -64,7 +65,7 @@ struct AssembleTab {
 };
 
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
-void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
+void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s);

@@ -115,74 +115,82 @@ struct KernFn<0, 0> {
     }
 };
 
-// great-circle pieces shared by the lld distance: a = haversine argument, g = km
+// ("lld","matern32"):  r = sqrt((g/l0)^2 + (dz/l1)^2),  k = sv (1 + sqrt3 r) exp(-sqrt3 r),  g = great-circle km
+// (run_seismic.py:19-63: haversine).  The gather stage turns every point into the record
+//     { sin(lat/2), cos(lat/2), sin(lon/2), cos(lon/2), depth }      (angles in radians, GEO_* below)
+// once per evaluation, so that a point PAIR needs no sin/cos at all: the half-difference sines and cosines of the
+// haversine come from the angle-difference identities (products of the two records; the cancellation happens before
+// the squaring, so a pair 1 km apart still has g to ~1e-12 relative), cos/sin(lat) from the double-angle ones.
+// What is left per pair is one sqrt + asin for g, one sqrt for r and one exp.
+constexpr int GEO_SLH = 0, GEO_CLH = 1, GEO_SNH = 2, GEO_CNH = 3, GEO_Z = 4, GEO_N = 5;
+constexpr int GEO_STRIDE = 8;       // doubles per gathered row of the lld instantiation (XPAD for the Euclidean one)
+
 struct Hav {
-    double a, g, s1, c1, s2, c2, cli, clj, slj;
+    double a, g, s1, c1, s2, c2, cli, clj, sli, slj;
 };
-__device__ static __forceinline__ Hav haversine(const double *xi, const double *xj) {
+__device__ static __forceinline__ Hav haversine(const double *gi, const double *gj) {
     Hav h;
-    double rloni = xi[0] * DEG2RAD, rlati = xi[1] * DEG2RAD;
-    double rlonj = xj[0] * DEG2RAD, rlatj = xj[1] * DEG2RAD;
-    double hl = (rlatj - rlati) / 2.0, hn = (rlonj - rloni) / 2.0;
-    h.s1 = sin(hl); h.c1 = cos(hl); h.s2 = sin(hn); h.c2 = cos(hn);
-    h.cli = cos(rlati); h.clj = cos(rlatj); h.slj = sin(rlatj);
+    h.s1 = gj[GEO_SLH] * gi[GEO_CLH] - gj[GEO_CLH] * gi[GEO_SLH];      // sin((lat_j - lat_i) / 2)
+    h.c1 = gj[GEO_CLH] * gi[GEO_CLH] + gj[GEO_SLH] * gi[GEO_SLH];
+    h.s2 = gj[GEO_SNH] * gi[GEO_CNH] - gj[GEO_CNH] * gi[GEO_SNH];      // sin((lon_j - lon_i) / 2)
+    h.c2 = gj[GEO_CNH] * gi[GEO_CNH] + gj[GEO_SNH] * gi[GEO_SNH];
+    h.cli = gi[GEO_CLH] * gi[GEO_CLH] - gi[GEO_SLH] * gi[GEO_SLH];
+    h.clj = gj[GEO_CLH] * gj[GEO_CLH] - gj[GEO_SLH] * gj[GEO_SLH];
+    h.sli = 2.0 * gi[GEO_SLH] * gi[GEO_CLH];
+    h.slj = 2.0 * gj[GEO_SLH] * gj[GEO_CLH];
     double a = h.s1 * h.s1 + h.cli * h.clj * h.s2 * h.s2;
     if (a > 1.0) a = 1.0;
     h.a = a;
-    double dist_rad = 2.0 * asin(sqrt(a));
-    double deg = dist_rad * (180.0 / 3.14159265358979323846);
-    h.g = (deg * DEG2RAD) * EARTH_R_KM;
+    h.g = 2.0 * asin(sqrt(a)) * EARTH_R_KM;
     return h;
 }
 
-// ("lld","matern32"):  r = sqrt((g/l0)^2 + (dz/l1)^2),  k = sv (1 + sqrt3 r) exp(-sqrt3 r)
 template <>
 struct KernFn<1, 1> {
-    __device__ static __forceinline__ double value(const KParams &p, const double *xi, const double *xj) {
-        Hav h = haversine(xi, xj);
+    __device__ static __forceinline__ double value(const KParams &p, const double *gi, const double *gj) {
+        Hav h = haversine(gi, gj);
         double dk = h.g / p.ls[0];
-        double dd = (xi[2] - xj[2]) / p.ls[1];
+        double dd = (gi[GEO_Z] - gj[GEO_Z]) / p.ls[1];
         double r = sqrt(dk * dk + dd * dd);
         double s3r = SQRT3 * r;
         return p.sv * (1.0 + s3r) * exp(-s3r);
     }
-    __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
-                                                  double *dkdxj, double *dkdl) {
-        Hav h = haversine(xi, xj);
+    // k(x_i, x_j) with the derivatives with respect to both ends and to the two lengthscales.  The great-circle
+    // derivatives are not antisymmetric in the two ends (d a / d lat has the other point's cos(lat) in it), but
+    // everything up to them — a, g, r, exp — is shared.
+    __device__ static __forceinline__ double pair(const KParams &p, const double *gi, const double *gj, bool, double,
+                                                  double *dkdxi, double *dkdxj, double *dkdl) {
+        Hav h = haversine(gi, gj);
         double l0 = p.ls[0], l1 = p.ls[1];
         double dk = h.g / l0;
-        double dz = xj[2] - xi[2];
+        double dz = gj[GEO_Z] - gi[GEO_Z];
         double dd = dz / l1;
         double r = sqrt(dk * dk + dd * dd);
         double s3r = SQRT3 * r;
         double e = exp(-s3r);
         double k = p.sv * (1.0 + s3r) * e;
         double c = -3.0 * p.sv * e;  // dk/dr = c * r ; r cancels against d r/d(.) = (.)/r
-        // g * dg/d(lon_j, lat_j): dg/da = R / sqrt(a(1-a)); zero at coincident / antipodal points
-        double gdg_lon = 0.0, gdg_lat = 0.0;
-        if (h.a > 0.0 && h.a < 1.0) {
-            double dg_da = EARTH_R_KM / sqrt(h.a * (1.0 - h.a));
-            double da_dlat = h.s1 * h.c1 - h.slj * h.cli * h.s2 * h.s2;
-            double da_dlon = h.cli * h.clj * h.s2 * h.c2;
-            gdg_lon = h.g * dg_da * da_dlon * DEG2RAD;
-            gdg_lat = h.g * dg_da * da_dlat * DEG2RAD;
-        }
-        dkdxj[0] = c * gdg_lon / (l0 * l0);
-        dkdxj[1] = c * gdg_lat / (l0 * l0);
-        dkdxj[2] = c * dz / (l1 * l1);
+        // g * dg/d(lon, lat): dg/da = R / sqrt(a(1-a)); zero at coincident / antipodal points
+        double w = 0.0;
+        if (h.a > 0.0 && h.a < 1.0) w = c * h.g * (EARTH_R_KM / sqrt(h.a * (1.0 - h.a))) * DEG2RAD / (l0 * l0);
+        double s22 = h.s2 * h.s2, s1c1 = h.s1 * h.c1;
+        double da_dlon = h.cli * h.clj * h.s2 * h.c2;
+        dkdxj[0] = w * da_dlon;
+        dkdxi[0] = -w * da_dlon;
+        dkdxj[1] = w * (s1c1 - h.slj * h.cli * s22);
+        dkdxi[1] = w * (-s1c1 - h.sli * h.clj * s22);
+        double tz = c * dz / (l1 * l1);
+        dkdxj[2] = tz;
+        dkdxi[2] = -tz;
         dkdl[0] = -c * h.g * h.g / (l0 * l0 * l0);
         dkdl[1] = -c * dz * dz / (l1 * l1 * l1);
         return k;
     }
-    // the great-circle derivatives are not antisymmetric in the two ends: evaluate both
-    __device__ static __forceinline__ double pair(const KParams &p, const double *xi, const double *xj, bool, double,
-                                                  double *dkdxi, double *dkdxj, double *dkdl) {
-        double tmp[3];
-        double k = full(p, xi, xj, dkdxj, dkdl);
-        (void)full(p, xj, xi, dkdxi, tmp);
-        return k;
-    }
 };
+
+// what a kernel instantiation keeps per point: row stride in the gathered pool and values held in registers
+template <int DIST> struct PtRec { static constexpr int STRIDE = XPAD, NREG = 3; };
+template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = GEO_N; };
 
 // ------------------------------------------------------------------------------------------------
 // gathers (gprf.py:300-302, 314-326: X[idxs], Y[idxs], vstack) into padded per-unit rows
@@ -199,10 +207,20 @@ __global__ void k_gather_y(const int32_t *__restrict__ upt, const double *__rest
 }
 
 __global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__restrict__ X, double *__restrict__ Xu,
-                           int dx, int total_rows) {
+                           int dx, int total_rows, int geo) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= total_rows) return;
     int pt = upt[row];
+    if (geo) {
+        // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
+        double lon = 0.0, lat = 0.0, z = 0.0;
+        if (pt >= 0) { lon = X[(size_t)pt * dx]; lat = X[(size_t)pt * dx + 1]; z = X[(size_t)pt * dx + 2]; }
+        double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
+        double *g = Xu + (size_t)row * GEO_STRIDE;
+        g[GEO_SLH] = sin(hl); g[GEO_CLH] = cos(hl); g[GEO_SNH] = sin(hn); g[GEO_CNH] = cos(hn); g[GEO_Z] = z;
+        g[5] = 0.0; g[6] = 0.0; g[7] = 0.0;
+        return;
+    }
     for (int d = 0; d < XPAD; ++d) {
         double v = 0.0;
         if (pt >= 0 && d < dx) v = X[(size_t)pt * dx + d];
@@ -219,7 +237,8 @@ __global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__rest
 // coalescing.  Halves the exp() work; the bytes written stay 8 mp^2 per unit.
 template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) {
-    __shared__ double xr[64 * XPAD];
+    constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
+    __shared__ double xr[64 * XS];
     int u = ut.ids[blockIdx.y];
     int m = ut.m[u];
     int mp = pad16(m);
@@ -230,16 +249,18 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
     while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
     int tj = ti + rem;
     int r0 = ti * 64, c0 = tj * 64;
-    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
+    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XS;
     int t = threadIdx.x;
-    {
-        int rr = r0 + (t >> 2);
-        xr[t] = (rr < mp) ? Xu[(size_t)rr * XPAD + (t & 3)] : 0.0;
+#pragma unroll
+    for (int e = t; e < 64 * XS; e += 256) {
+        int rr = r0 + e / XS;
+        xr[e] = (rr < mp) ? Xu[(size_t)r0 * XS + e] : 0.0;
     }
     int cl = t & 63;
     int col = c0 + cl;
-    double xj[XPAD];
-    for (int d = 0; d < XPAD; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XPAD + d] : 0.0;
+    double xj[XN];
+#pragma unroll
+    for (int d = 0; d < XN; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XS + d] : 0.0;
     __syncthreads();
     double *U = pl.K + ut.mat_off[u];     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
     double diag_add = kp.nv + ut.jitter[u];
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
         double v = 0.0;
         if (row < mp && col < mp) {
             if (row < m && col < m) {
-                v = KernFn<DIST, KERN>::value(kp, &xr[rl * XPAD], xj);
+                v = KernFn<DIST, KERN>::value(kp, &xr[rl * XS], xj);
                 if (row == col) v += diag_add;
             } else {
                 v = (row == col) ? 1.0 : 0.0;
@@ -1637,17 +1658,17 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
     double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
     const double *__restrict__ Kp = pl.K + ut.mat_off[u];
-    const double *__restrict__ Xu = pl.Xu + roff * XPAD;
+    constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
+    const double *__restrict__ Xu = pl.Xu + roff * XS;
     const int tbs = TBm;                               // stride of the per-block partials
-    double rowsum[4][3], xi[4][3];
+    double rowsum[4][3], xi[4][XN];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int i = 16 * I + lg + 4 * q;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            rowsum[q][d] = 0.0;
-            xi[q][d] = active ? Xu[(size_t)i * XPAD + d] : 0.0;
-        }
+        for (int d = 0; d < 3; ++d) rowsum[q][d] = 0.0;
+#pragma unroll
+        for (int d = 0; d < XN; ++d) xi[q][d] = active ? Xu[(size_t)i * XS + d] : 0.0;
     }
     double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
     double csum[4][3];
@@ -1666,9 +1687,9 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     if (active && diagblk) {                           // wave-uniform
         d4 md = wave == 0 ? acc[0] : (wave == 1 ? acc[1] : (wave == 2 ? acc[2] : acc[3]));
         int j = 16 * I + lr;
-        double xj[3];
+        double xj[XN];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
+        for (int d = 0; d < XN; ++d) xj[d] = Xu[(size_t)j * XS + d];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = 16 * I + lg + 4 * q;
@@ -1712,11 +1733,12 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         if (need[jj] && J0 + jj < I) {                 // wave-uniform
             int J = J0 + jj;
             int j = 16 * J + lr;
-            double xj[3], Kv[4];
+            double xj[XN], Kv[4];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) xj[d] = Xu[(size_t)j * XPAD + d];
+            for (int d = 0; d < XN; ++d) xj[d] = Xu[(size_t)j * XS + d];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
+                if constexpr (DIST == 0 && KERN == 0)
                 Kv[q] = diagblk ? Kp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr]      // diagonal blocks are whole
                                 : Kp[(size_t)(16 * J + lr) * mp + 16 * I + lg + 4 * q];     // K(i,j) = K(j,i)
 #pragma unroll
@@ -1975,9 +1997,10 @@ void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy,
     hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);
 }
 
-void launch_gather_x(const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s) {
+void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s) {
     if (total_rows == 0) return;
-    hipLaunchKernelGGL(k_gather_x, dim3((total_rows + 255) / 256), dim3(256), 0, s, ut.upt, X, p.Xu, dx, total_rows);
+    hipLaunchKernelGGL(k_gather_x, dim3((total_rows + 255) / 256), dim3(256), 0, s, ut.upt, X, p.Xu, dx, total_rows,
+                       dist_id == 1 ? 1 : 0);
 }
 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {

@@ -58,7 +58,9 @@ def threshold_neighbors(X, block_idxs, cov, threshold):
     distance between two blocks' bounding boxes bounds every point pair from below, and both kernels decrease
     with distance, so a pair whose boxes are already too far apart cannot qualify and is skipped.  The surviving
     pairs are decided by the same full cross matrix as before: identical result (the C4 configuration's 353 k
-    block pairs shrink to a few thousand candidates).  Other distances take the exhaustive route."""
+    block pairs shrink to a few thousand candidates).  For "lld" the bound is the great-circle distance between two
+    blocks' spherical caps (centre distance minus both angular radii: the great-circle distance is a metric) combined
+    with the gap between their depth ranges, less a margin that covers the haversine's rounding."""
     X = np.asarray(X, dtype=np.float64)
     nb = len(block_idxs)
     pairs = []
@@ -79,6 +81,32 @@ def threshold_neighbors(X, block_idxs, cov, threshold):
             # gap between box i and every box j < i along each axis (0 where they overlap)
             gap = np.maximum(0.0, np.maximum(lo[i][None, :] - hi[:i], lo[:i] - hi[i][None, :]))
             dmin = np.sqrt(np.sum(gap * gap, axis=1))
+            cand = np.nonzero(_unit_kernel_of_distance(dmin, cov) > threshold)[0]
+            for j in cand:
+                if nonempty[j] and cross_kernel_max(X[block_idxs[i]], X[block_idxs[j]], cov) > threshold:
+                    pairs.append((i, int(j)))
+        return pairs
+    if cov.dfn_str == "lld":
+        ls = np.asarray(cov.dfn_params, dtype=np.float64)
+        clon, clat, rad = np.zeros(nb), np.zeros(nb), np.full(nb, np.inf)
+        zlo, zhi = np.full(nb, np.inf), np.full(nb, -np.inf)
+        for i, b in enumerate(block_idxs):
+            if nonempty[i]:
+                lon, lat = np.radians(X[b, 0]), np.radians(X[b, 1])
+                c = np.array([np.mean(np.cos(lat) * np.cos(lon)), np.mean(np.cos(lat) * np.sin(lon)), np.mean(np.sin(lat))])
+                if np.linalg.norm(c) > 1e-6:            # (a block spread over the whole globe keeps an infinite cap)
+                    c /= np.linalg.norm(c)
+                    clon[i], clat[i] = np.degrees(np.arctan2(c[1], c[0])), np.degrees(np.arcsin(np.clip(c[2], -1, 1)))
+                    rad[i] = np.max(great_circle_km(clon[i], clat[i], X[b, 0], X[b, 1]))
+                zlo[i], zhi[i] = X[b, 2].min(), X[b, 2].max()
+        for i in range(1, nb):
+            if not nonempty[i]:
+                continue
+            gc = great_circle_km(clon[i], clat[i], clon[:i], clat[:i]) - rad[i] - rad[:i]
+            gc = np.where(np.isfinite(gc), np.maximum(0.0, gc * (1 - 1e-9) - 1e-6), 0.0)
+            zgap = np.maximum(0.0, np.maximum(zlo[i] - zhi[:i], zlo[:i] - zhi[i]))
+            zgap = np.where(np.isfinite(zgap), zgap * (1 - 1e-12), 0.0)
+            dmin = np.sqrt((gc / ls[0]) ** 2 + (zgap / ls[1]) ** 2)
             cand = np.nonzero(_unit_kernel_of_distance(dmin, cov) > threshold)[0]
             for j in cand:
                 if nonempty[j] and cross_kernel_max(X[block_idxs[i]], X[block_idxs[j]], cov) > threshold:

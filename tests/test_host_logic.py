@@ -169,3 +169,30 @@ def test_threshold_neighbors_pruned_equals_exhaustive_oracle():
         ref = GPRFRef(X, Y, None, OC([1.3], ls, "euclidean", wfn), 0.01, block_idxs=blocks, neighbors=[])
         ref.compute_neighbors(threshold=thr)
         assert got == [(int(i), int(j)) for (i, j) in ref.neighbors], (wfn, ls, thr)
+
+
+def test_threshold_neighbors_lld_cap_pruning_equals_exhaustive_oracle():
+    """Same for the seismic distance: spherical-cap + depth-range pruning returns the oracle's exhaustive pair list,
+    including blocks across the date line, near a pole, an empty block and two interleaved blocks."""
+    from gprf_amd import GPCov, seismic
+    from gprf_amd.hostkernels import threshold_neighbors
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    X = seismic.synthetic_events(1500, seed=2)
+    rng = np.random.RandomState(0)
+    polar = np.stack([rng.uniform(-180, 180, 60), rng.uniform(86, 89.9, 60), rng.exponential(30, 60)], axis=1)
+    X = np.concatenate([X, polar])
+    Y = np.zeros((len(X), 1))
+    blocks, _ = seismic.pdtree_cluster(X, blocksize=70)
+    blocks = [np.asarray(b) for b in blocks]
+    blocks[5] = np.zeros(0, dtype=np.int64)
+    blocks[2], blocks[9] = np.concatenate([blocks[2][::2], blocks[9][::2]]), np.concatenate([blocks[2][1::2], blocks[9][1::2]])
+    total = 0
+    for wfn, ls, thr in (("matern32", [40.0, 40.0], 0.6), ("matern32", [150.0, 20.0], 0.3), ("se", [300.0, 50.0], 1e-3),
+                         ("matern32", [40.0, 40.0], 1.0), ("matern32", [2000.0, 500.0], 1e-4)):
+        got = threshold_neighbors(X, blocks, GPCov([0.7], ls, "lld", wfn), thr)
+        ref = GPRFRef(X, Y, None, OC([0.7], ls, "lld", wfn), 0.1, block_idxs=blocks, neighbors=[])
+        ref.compute_neighbors(threshold=thr)
+        assert got == [(int(i), int(j)) for (i, j) in ref.neighbors], (wfn, ls, thr)
+        total += len(got)
+    assert total > 50
