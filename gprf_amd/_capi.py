@@ -35,6 +35,7 @@ SIGNATURES = {
     "gprf_set_block_assignment": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_set_centers": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_assign_blocks": (ctypes.c_int, [_vp, _dp, _i32p, _i32p]),
+    "gprf_set_split_tree": (ctypes.c_int, [_vp, _i32, _i32, _i32, _dp, _dp, _dp, _i32p, _i32p, _i32p]),
     "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
     "gprf_partition_units": (ctypes.c_int, [_i32, _i32p, _i32, _i32, _i32p]),
     "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
@@ -190,6 +191,18 @@ class Context(object):
         centers = np.ascontiguousarray(centers, dtype=np.float64)
         assert centers.ndim == 2 and centers.shape[1] == self.dx
         self._check(self.lib.gprf_set_centers(self.h, centers.shape[0], dptr(centers)), "gprf_set_centers")
+
+    def set_split_tree(self, vec, center, split, left, right, leaf_block, lon_wrap):
+        """Route gprf_assign_blocks through a binary split tree (see include/gprf_hip.h)."""
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        center = np.ascontiguousarray(center, dtype=np.float64)
+        split = np.ascontiguousarray(split, dtype=np.float64)
+        left, right, leaf_block = (np.ascontiguousarray(a, dtype=np.int32) for a in (left, right, leaf_block))
+        n_nodes, dim = vec.shape
+        assert center.shape == (n_nodes, dim) and split.shape == left.shape == right.shape == leaf_block.shape == (n_nodes,)
+        self._check(self.lib.gprf_set_split_tree(self.h, n_nodes, dim, 1 if lon_wrap else 0, dptr(vec), dptr(center),
+                                                 dptr(split), left.ctypes.data_as(_i32p), right.ctypes.data_as(_i32p),
+                                                 leaf_block.ctypes.data_as(_i32p)), "gprf_set_split_tree")
 
     def assign_blocks(self, X):
         """Device re-blocking: -> (changed, block_of or None).  When ``changed`` the context has already installed

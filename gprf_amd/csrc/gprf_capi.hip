@@ -101,6 +101,10 @@ struct gprf_ctx {
     PinBuf<int32_t> h_assign, h_changed;
     int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
     int n_centers = 0;
+    // ... or through a split tree (gprf_set_split_tree): node arrays, leaf -> block id
+    DevBuf<double> d_tvec, d_tcenter, d_tsplit;
+    DevBuf<int32_t> d_tleft, d_tright, d_tleaf;
+    int tree_nodes = 0, tree_dim = 0, tree_wrap = 0;
     bool assign_valid = false;            // d_assign holds the partition the unit tables were built from
     DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
@@ -701,13 +705,59 @@ int gprf_set_centers(gprf_ctx *c, int32_t nc, const double *centers) {
     HIP_TRY(c, hipMemcpy(c->d_c2.p, c2.data(), c2.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t)));   // -1: everybody "moves" first time
     c->n_centers = nc;
+    c->tree_nodes = 0;
+    c->assign_valid = false;
+    return GPRF_OK;
+}
+
+int gprf_set_split_tree(gprf_ctx *c, int32_t n_nodes, int32_t dim, int32_t lon_wrap, const double *vec,
+                        const double *center, const double *split, const int32_t *left, const int32_t *right,
+                        const int32_t *leaf_block) {
+    if (!c || n_nodes < 1 || dim < 1 || !vec || !center || !split || !left || !right || !leaf_block) return GPRF_ERR_ARG;
+    if (dim > c->dx || dim > 8) return fail(c, GPRF_ERR_ARG, "tree dimension exceeds the point dimension");
+    // a well-formed tree: children point forward (so every descent ends), leaves carry distinct block ids 0..n_leaves-1
+    int n_leaves = 0;
+    for (int k = 0; k < n_nodes; ++k) {
+        if (left[k] < 0) { ++n_leaves; continue; }
+        if (left[k] <= k || left[k] >= n_nodes || right[k] <= k || right[k] >= n_nodes)
+            return fail(c, GPRF_ERR_ARG, "tree children must have larger node ids than their parent");
+    }
+    std::vector<char> seen((size_t)n_leaves, 0);
+    for (int k = 0; k < n_nodes; ++k) {
+        if (left[k] >= 0) continue;
+        int b = leaf_block[k];
+        if (b < 0 || b >= n_leaves || seen[b]) return fail(c, GPRF_ERR_ARG, "leaf block ids must be a permutation of 0..n_leaves-1");
+        seen[b] = 1;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t nd = (size_t)n_nodes * dim;
+    HIP_TRY(c, c->d_tvec.reserve(nd + 1));
+    HIP_TRY(c, c->d_tcenter.reserve(nd + 1));
+    HIP_TRY(c, c->d_tsplit.reserve((size_t)n_nodes + 1));
+    HIP_TRY(c, c->d_tleft.reserve((size_t)n_nodes + 1));
+    HIP_TRY(c, c->d_tright.reserve((size_t)n_nodes + 1));
+    HIP_TRY(c, c->d_tleaf.reserve((size_t)n_nodes + 1));
+    HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1));
+    HIP_TRY(c, c->d_changed.reserve(1));
+    HIP_TRY(c, c->h_assign.reserve((size_t)c->n + 1));
+    HIP_TRY(c, c->h_changed.reserve(1));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_tvec.p, vec, nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tcenter.p, center, nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tsplit.p, split, (size_t)n_nodes * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tleft.p, left, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tright.p, right, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tleaf.p, leaf_block, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t)));
+    c->tree_nodes = n_nodes; c->tree_dim = dim; c->tree_wrap = lon_wrap ? 1 : 0;
+    c->n_centers = n_leaves;
     c->assign_valid = false;
     return GPRF_OK;
 }
 
 int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *block_of_out) {
     if (!c || !X || !changed) return GPRF_ERR_ARG;
-    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers first");
+    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
@@ -715,7 +765,11 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
     HIP_TRY(c, hipMemsetAsync(c->d_changed.p, 0, sizeof(int32_t), s));
     memcpy(c->h_X.p, X, nx * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_assign(c->d_X.p, c->n, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, c->d_assign.p, c->d_changed.p, s);
+    if (c->tree_nodes > 0)
+        launch_route(c->d_X.p, c->n, c->dx, c->tree_dim, c->tree_wrap, c->d_tvec.p, c->d_tcenter.p, c->d_tsplit.p,
+                     c->d_tleft.p, c->d_tright.p, c->d_tleaf.p, c->d_assign.p, c->d_changed.p, s);
+    else
+        launch_assign(c->d_X.p, c->n, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, c->d_assign.p, c->d_changed.p, s);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_changed.p, c->d_changed.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

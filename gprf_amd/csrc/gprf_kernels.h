@@ -64,6 +64,9 @@ struct AssembleTab {
     const double *slot_w;      // unit weight
 };
 
+void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+                  const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
+                  int32_t *block_of, int32_t *changed, hipStream_t s);
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
 void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);

@@ -1992,6 +1992,49 @@ void launch_assign(const double *X, int n, int dx, const double *cs, const doubl
     hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, s, X, n, dx, cs, c2, nc, block_of, changed);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_route: the seismic driver's re-blocking (pdtree_clustering.py:65-94 via gprf.py:171-172): every point descends
+// the principal-direction tree — (x - center_k) . vec_k < split_k ? left : right — one thread per point, the
+// longitude first moved to [-22, 338) like the reference's `(lon + 22) % 360 - 22`.  The projection is accumulated
+// column by column with separately rounded multiplies and adds, which is how gprf_amd/seismic.py builds and routes
+// (numpy element-wise ops): bit-identical decisions, including the median point whose projection equals the split.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, int n, int dx, int dim, int lon_wrap,
+                                               const double *__restrict__ vec, const double *__restrict__ center,
+                                               const double *__restrict__ split, const int32_t *__restrict__ left,
+                                               const int32_t *__restrict__ right, const int32_t *__restrict__ leaf_block,
+                                               int32_t *__restrict__ block_of, int32_t *__restrict__ changed) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double x[8];
+    for (int d = 0; d < dim; ++d) x[d] = X[(size_t)p * dx + d];
+    if (lon_wrap) {
+        double r = fmod(__dadd_rn(x[0], 22.0), 360.0);          // numpy's %: the result takes the divisor's sign
+        if (r != 0.0) { if (r < 0.0) r = __dadd_rn(r, 360.0); } else r = 0.0;
+        x[0] = __dsub_rn(r, 22.0);
+    }
+    int k = 0;
+    while (left[k] >= 0) {
+        double a = __dmul_rn(__dsub_rn(x[0], center[(size_t)k * dim]), vec[(size_t)k * dim]);
+        for (int d = 1; d < dim; ++d)
+            a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
+        k = (a < split[k]) ? left[k] : right[k];
+    }
+    int best = leaf_block[k];
+    if (block_of[p] != best) {
+        block_of[p] = best;
+        *changed = 1;            // benign race: every writer stores the same value
+    }
+}
+
+void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+                  const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
+                  int32_t *block_of, int32_t *changed, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_route, dim3((n + 255) / 256), dim3(256), 0, s, X, n, dx, dim, lon_wrap, vec, center, split, left,
+                       right, leaf_block, block_of, changed);
+}
+
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
     if (total_rows == 0) return;
     hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);

@@ -99,6 +99,8 @@ class GPRF(object):
             order = np.argsort(self._block_of, kind="stable")
             counts = np.bincount(self._block_of, minlength=self.n_blocks)
             self._block_idxs = np.split(order, np.cumsum(counts)[:-1])
+            if self._blocks_pushed == "assignment":
+                self._blocks_pushed = self._block_idxs      # the library already holds exactly this partition
         return self._block_idxs
 
     @block_idxs.setter
@@ -155,12 +157,14 @@ class GPRF(object):
         """gprf.py:169-174: rebinding X re-runs block_fn on every call; the neighbour list stays.
 
         When ``block_fn`` is the ``block_clusters`` method of a grid ``Blocker`` the assignment runs in the C
-        library (gprf_nearest_center + gprf_set_block_assignment) and ``block_idxs`` is materialised only if
-        somebody reads it."""
+        library (gprf_set_centers + gprf_assign_blocks) and ``block_idxs`` is materialised only if somebody reads
+        it; the same for the ``reblock`` of ``seismic.pdtree_cluster`` (gprf_set_split_tree)."""
         self.X = new_X
         if self.block_fn is not None:
             blocker = getattr(self.block_fn, "__self__", None)
+            tree = getattr(self.block_fn, "tree", None)
             from .blocking import Blocker
+            device_route = None
             if isinstance(blocker, Blocker) and getattr(self.block_fn, "__name__", "") == "block_clusters" \
                     and blocker.n_blocks == self.n_blocks:
                 # nearest-centre assignment on the device; the partition comes back to the host (and the unit
@@ -168,6 +172,15 @@ class GPRF(object):
                 if getattr(self, "_centers_of", None) is not blocker:
                     self._ctx.set_centers(blocker.block_centers)
                     self._centers_of = blocker
+                device_route = blocker
+            elif tree is not None and hasattr(tree, "leaf_block") and len(tree.leaf_order) == self.n_blocks:
+                # seismic.pdtree_cluster's reblock: the same, descending the split tree on the device
+                if getattr(self, "_centers_of", None) is not tree:
+                    self._ctx.set_split_tree(tree.vec, tree.center, tree.split, tree.left, tree.right, tree.leaf_block,
+                                             getattr(self.block_fn, "lon_wrap", False))
+                    self._centers_of = tree
+                device_route = tree
+            if device_route is not None:
                 Xc = np.ascontiguousarray(new_X, dtype=np.float64)
                 changed, block_of = self._ctx.assign_blocks(Xc)
                 if changed:

@@ -74,6 +74,8 @@ class PDTree(object):
         self.split, self.left, self.right = np.array(split), np.array(left), np.array(right)
         # with left-first depth-first numbering the leaves appear left to right in increasing node id
         self.leaf_order = [k for k in range(len(self.left)) if self.left[k] < 0]
+        self.leaf_block = np.full(len(self.left), -1, dtype=np.int32)      # node id -> block index (leaves only)
+        self.leaf_block[self.leaf_order] = np.arange(len(self.leaf_order), dtype=np.int32)
         self._build_leaves = [leaf_pts[k] for k in self.leaf_order]
 
     def leaf_idx(self):
@@ -109,7 +111,10 @@ def pdtree_cluster(X, blocksize=300):
         Z[:, 0] = wrap_longitude(Z[:, 0])
         return tree.recluster(Z)
 
+    # GPRF.update_X recognises these two attributes and routes on the device (gprf_set_split_tree); calling reblock
+    # itself stays the host path
     reblock.tree = tree
+    reblock.lon_wrap = True
     return tree.leaf_idx(), reblock
 
 

@@ -87,6 +87,17 @@ int gprf_set_block_assignment(gprf_ctx *ctx, int32_t n_blocks, const int32_t *bl
 int gprf_set_centers(gprf_ctx *ctx, int32_t n_centers, const double *centers);
 int gprf_assign_blocks(gprf_ctx *ctx, const double *X, int32_t *changed, int32_t *block_of_out);
 
+/* The same for the seismic driver's partition (run_seismic.py:375 passes pdtree_cluster's reblock as
+ * block_fn, pdtree_clustering.py:65-94): a binary split tree of n_nodes nodes, node 0 the root, children with larger
+ * ids than their parent; node k is a leaf when left[k] < 0 and then stands for block leaf_block[k] (a permutation of
+ * 0..n_leaves-1), otherwise a point goes left when (x[0:dim] - center[k]) . vec[k] < split[k] (projection accumulated
+ * column by column, multiplies and adds rounded separately) and right otherwise.  lon_wrap != 0 first maps x[0] to
+ * (x[0] + 22) % 360 - 22 (pdtree_clustering.py:82).  vec/center are n_nodes x dim row-major.  After this call
+ * gprf_assign_blocks routes through the tree (n_blocks = n_leaves) until gprf_set_centers is called again. */
+int gprf_set_split_tree(gprf_ctx *ctx, int32_t n_nodes, int32_t dim, int32_t lon_wrap, const double *vec,
+                        const double *center, const double *split, const int32_t *left, const int32_t *right,
+                        const int32_t *leaf_block);
+
 /* self.neighbors (gprf.py:112,212): n_pairs rows (i, j); each becomes one joint unit with block i's rows
  * first (gprf.py:322).  Bethe weights 1 - deg(i) for the unaries are derived here
  * (compute_neighbor_count gprf.py:152-157; llgrad gprf.py:253-254, 264, 287).  For local=False pass all

@@ -74,3 +74,39 @@ def test_short_optimisation_improves_objective_and_locations():
     f0, _ = seismic.SeismicObjective(g, Xobs, None, x_prior=xp)(obj.full0)
     assert res.fun < f0
     g.close()
+
+
+def test_device_tree_routing_equals_host_routing():
+    """GPRF.update_X with pdtree_cluster's reblock routes on the device (gprf_set_split_tree + gprf_assign_blocks,
+    kernel k_route): the partition is bit-for-bit the host routine's — for the build points themselves (every split's
+    median point sits exactly on its threshold), for moved points, across the date line, and with a leaf left empty —
+    and the evaluation equals one driven through the plain-callable (host) path."""
+    from gprf_amd import GPCov, seismic
+    from gprf_amd.gprf import GPRF
+    n = 3000
+    X = seismic.synthetic_events(n, seed=5)
+    X[:40, 0] = np.where(np.arange(40) % 2 == 0, 179.9, -179.9) + np.linspace(-0.05, 0.05, 40)   # date-line cluster
+    Y = np.random.RandomState(0).randn(n, 3)
+    cov = GPCov([1.0], [150.0, 150.0], "lld", "matern32")
+    blocks, reblock = seismic.pdtree_cluster(X, blocksize=120)
+    g = GPRF(X, Y, reblock, cov, 0.1, neighbor_threshold=0.6)
+    slow = GPRF(X, Y, lambda Z: reblock(Z), cov, 0.1, neighbors=g.neighbors, block_idxs=blocks)
+    slow.block_fn = lambda Z: reblock(Z)
+    rng = np.random.RandomState(1)
+    moves = [X, X + rng.randn(n, 3) * [0.3, 0.3, 3.0], X + rng.randn(n, 3) * [5.0, 5.0, 20.0]]
+    far = X.copy(); far[np.asarray(blocks[3])] += [40.0, 10.0, 0.0]                               # block 3 empties
+    moves.append(far)
+    for k, X2 in enumerate(moves):
+        g.update_X(X2)
+        host = reblock(X2)
+        assert len(g.block_idxs) == len(host)
+        assert all(np.array_equal(a, b) for a, b in zip(g.block_idxs, host)), k
+        slow.update_X(X2)
+        a, b = g.llgrad(grad_X=True, grad_cov=True), slow.llgrad(grad_X=True, grad_cov=True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert g._centers_of is reblock.tree                     # the device path was the one taken
+    assert any(len(b) == 0 for b in g.block_idxs)
+    # unchanged points: no partition comes back
+    changed, _ = g._ctx.assign_blocks(np.ascontiguousarray(far))
+    assert not changed
+    g.close(); slow.close()
