@@ -1235,7 +1235,8 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
 }
 
 
-constexpr int SOLVE_PANEL_MAXT = 18;  // largest k_solve_panel instantiation (accumulators: 18 tiles x 8 VGPRs)
+constexpr int SOLVE_PANEL_MAXT = 28;  // largest k_solve_panel instantiation (accumulators: 28 tiles x 8 registers,
+                                      // one workgroup per CU: 448 points cover the seismic configuration's pairs)
 
 // k_solve_panel: the same forward substitution with the U row panel of each step staged ONCE per workgroup in LDS
 // (cooperative, coalesced loads of panel r+1 overlap step r's MFMAs; one barrier per step), so the four waves
@@ -1275,9 +1276,11 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     const double *__restrict__ Yu = pl.Yu + roff * YPAD;
     int r0 = is_y ? 0 : cb;
 
+    // (static_for, not "#pragma unroll": the optimizer gives up on the 28-tile instantiation's loops and the
+    // accumulators would land in scratch)
     d4 acc[MAXT];
-#pragma unroll
-    for (int r = 0; r < MAXT; ++r) {
+    static_for<0, MAXT>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double v = 0.0;
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
             }
             acc[r][q] = v;
         }
-    }
+    });
     // staging registers: wave w carries rows 4w..4w+3 of the panel, NCH column chunks of 64, plus one V entry
     double pre[4][NCH], prev;
     auto fetch = [&](int r) {
@@ -1316,8 +1319,8 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
 #else
 #define GPRF_SST(k)
 #endif
-#pragma unroll
-    for (int r = 0; r < MAXT; ++r) {
+    static_for<0, MAXT>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         if (r >= rmin && r < T) {                 // uniform over the workgroup
             double *buf = panel[r & 1];
 #pragma unroll
@@ -1353,17 +1356,17 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
                 }
                 GPRF_SST(3)
                 const double *pr = buf + lg * LDP + lr;
-#pragma unroll
-                for (int r2 = r + 1; r2 < MAXT; ++r2) {
+                static_for<r + 1, MAXT>([&](auto r2c) {
+                    constexpr int r2 = decltype(r2c)::value;
                     if (r2 < T) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * r2], w[s], acc[r2]);
                     }
-                }
+                });
                 GPRF_SST(4)
             }
         }
-    }
+    });
 #ifdef GPRF_PROFILE
     if (stamp && lane == 0) {
         for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
@@ -2092,7 +2095,8 @@ void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
         dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
         if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve_panel<12, 3>), grid, dim3(256), 0, s, ut, p);
-        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 2>), grid, dim3(256), 0, s, ut, p);
+        else if (ut.max_T <= 18) hipLaunchKernelGGL((k_solve_panel<18, 2>), grid, dim3(256), 0, s, ut, p);
+        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1>), grid, dim3(256), 0, s, ut, p);
         return;
     }
     // units of more than 288 points: accumulators no longer fit the register budget -> LDS-broadcast form

@@ -276,7 +276,10 @@ def test_device_reblocking_matches_host_and_oracle():
                                          (3, 7, [200, 150]), (2, 50, [257, 255]),
                                          # pair units of exactly 14 / 15 / 16 tiles: the register-resident Cholesky's
                                          # three tile-dealing regimes (wave 0 free / overflow only / a full share)
-                                         (2, 9, [112, 112, 120, 120, 128, 128, 127])])
+                                         (2, 9, [112, 112, 120, 120, 128, 128, 127]),
+                                         # the seismic configuration's largest pairs (blocks of up to 209 events):
+                                         # 27 and 28 tiles, the one-workgroup-per-CU instantiation of k_solve_panel
+                                         (3, 5, [209, 209, 30, 224, 224])])
 def test_random_shapes_against_oracle(dx, dy, sizes):
     """SE kernel with 1-3 input dimensions, 1..64 output columns (64 = the padded width), ragged block sizes incl.
     tile-boundary cases (16, 64, 255/257 -> pair of 512), chain of pairs + one long-range pair."""
