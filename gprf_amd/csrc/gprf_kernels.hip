@@ -1643,11 +1643,13 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
         // the -dy of the W part rides on the A operand (4 multiplies per chunk): the accumulators are never
         // rescaled in the middle of the chunk loop
+#ifndef GPRF_ABL_MG_NOMMA
         if (c < nchW) {
             if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd, 4);
         } else {
             if (active) mma_chunk(buf, 1.0, (c == nch - 1) ? ks_last : 4);
         }
+#endif
     };
     fetch0(0);
     if (nch > 1) fetch1(1);
@@ -1687,7 +1689,12 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     // the wave's diagonal tile (diagonal block pairs only; it is tile jj == wave): k re-evaluated from the
     // coordinates (the pool holds U there), column sums only
     double csd[3] = {0.0, 0.0, 0.0};
-    if (active && diagblk) {                           // wave-uniform
+#ifdef GPRF_ABL_MG_NOEPI
+    const bool epi = kp.dy < 0;                        // (never: the reductions are compiled but skipped)
+#else
+    constexpr bool epi = true;
+#endif
+    if (epi && active && diagblk) {                    // wave-uniform
         d4 md = wave == 0 ? acc[0] : (wave == 1 ? acc[1] : (wave == 2 ? acc[2] : acc[3]));
         int j = 16 * I + lr;
         double xj[XN];
@@ -1733,7 +1740,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     for (int jj = 0; jj < 4; ++jj) {
         bool mydiag = diagblk && jj == wave;
         double colsum[3] = {mydiag ? csd[0] : 0.0, mydiag ? csd[1] : 0.0, mydiag ? csd[2] : 0.0};
-        if (need[jj] && J0 + jj < I) {                 // wave-uniform
+        if (epi && need[jj] && J0 + jj < I) {          // wave-uniform
             int J = J0 + jj;
             int j = 16 * J + lr;
             double xj[XN], Kv[4];
