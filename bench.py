@@ -287,7 +287,22 @@ def main():
             pass
         roof["avg_launch_ms"] = stage[dom]
         roof["algorithmic_per_launch"] = fl["fill_bytes"] if dom == "fill" else fl[dom]
-        roof["fill_GBps"] = fl["fill_bytes"] / (stage["fill"] * 1e-3) / 1e9
+        if world == 1:
+            # K is generated inside k_potrf_reg on this configuration and k_fill does not run; the fill kernel's
+            # HBM write rate is measured on the side by forcing the K pool back for a few evaluations
+            os.environ["GPRF_FUSED_FILL"] = "0"
+            e = evs[0]
+            e.g._ctx.set_timing(True, reset=True)
+            for _ in range(8):
+                e.enqueue(True, grad_cov, stream=run_stream)
+            torch.cuda.synchronize()
+            tmf = e.g._ctx.get_timing()
+            e.g._ctx.set_timing(False, reset=True)
+            del os.environ["GPRF_FUSED_FILL"]
+            roof["fill_kernel"] = {"GBps": fl["fill_bytes"] / (tmf["fill"] * 1e-3) / 1e9, "ms": tmf["fill"],
+                                   "potrf_ms_reading_K": tmf["potrf"],
+                                   "note": "k_fill timed with GPRF_FUSED_FILL=0; by default k_potrf_reg generates K "
+                                           "and it never exists in HBM (stages_ms.fill is then two event records)"}
         roof["mfma_f64_measured_peak"] = FP64_MFMA_MEASURED_TFLOPS
         roof["whole_eval_TFLOPs"] = total_all * value / 1e12
         roof["whole_eval_frac_of_fp64_peak"] = total_all * value / 1e12 / (FP64_PEAK_TFLOPS * world)

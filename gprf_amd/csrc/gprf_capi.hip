@@ -429,16 +429,18 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         mark();
         launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, (int)c->total_rows, s);
         mark();
-        launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
+        // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
+        bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
+        if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
         mark();
-        if (stop_after >= 1) launch_potrf(ut, pl, s);
+        if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s);
         mark();
         if (stop_after >= 2) launch_solve(ut, pl, s);
         mark();
         if (stop_after >= 3) launch_at(ut, pl, s);
         mark();
         if (do_grad) {
-            launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, (int)c->total_rows, s);
+            launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, (int)c->total_rows, !gen, s);
             launch_gx_finalize(ut, pl, (int)c->total_rows, s);
         }
         mark();
@@ -461,11 +463,12 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
             ug.n_ids = c->group_begin[g + 1] - c->group_begin[g];
             hipStream_t gs = c->gstream[g];
             HIP_TRY(c, hipStreamWaitEvent(gs, c->gev_start, 0));
-            launch_fill(c->dist_id, c->kern_id, ug, pl, kp, gs);
-            if (stop_after >= 1) launch_potrf(ug, pl, gs);
+            bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ug);
+            if (!gen) launch_fill(c->dist_id, c->kern_id, ug, pl, kp, gs);
+            if (stop_after >= 1) launch_potrf(ug, pl, kp, gen, gs);
             if (stop_after >= 2) launch_solve(ug, pl, gs);
             if (stop_after >= 3) launch_at(ug, pl, gs);
-            if (do_grad) launch_grad(c->dist_id, c->kern_id, ug, pl, kp, want_gc, (int)c->total_rows, gs);
+            if (do_grad) launch_grad(c->dist_id, c->kern_id, ug, pl, kp, want_gc, (int)c->total_rows, !gen, gs);
             HIP_TRY(c, hipEventRecord(c->gev_done[g], gs));
             HIP_TRY(c, hipStreamWaitEvent(s, c->gev_done[g], 0));
         }

@@ -70,11 +70,12 @@ void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const d
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
 void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
-void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s);
+bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s);
 void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 int total_rows, hipStream_t s);
+                 int total_rows, bool have_K, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s);

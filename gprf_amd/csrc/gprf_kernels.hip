@@ -73,6 +73,58 @@ constexpr double SQRT3 = 1.7320508075688772935;
 template <int DIST, int KERN>
 struct KernFn;
 
+// exp(x) for the covariance functions' arguments (x <= 0 in exact arithmetic; any finite x works): n = rint(x log2 e),
+// r = x - n ln2 (two-piece ln2, |r| <= 0.347), Taylor polynomial of degree 13 (truncation 4e-18 relative), ldexp.
+// The library exp() spends half of its ~40 instructions moving polynomial coefficients into VGPRs for v_fmac; here
+// every Horner step is one v_fma_f64 with the coefficient as a scalar operand — 20 instructions.  That matters where
+// a wave is alone on its SIMD and generates kernel values itself (k_potrf_reg<.,.,true>).  NaN stays NaN, anything
+// below -745.2 (the smallest subnormal's logarithm) is 0, including -inf.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_scalar) {
+    double d;
+    // (volatile: the step-major order of exp_fast_v is the point, the scheduler would re-serialise the chains)
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+    return d;
+}
+// N independent arguments, written step-major: the N dependent chains advance together (a lone wave has nothing
+// else to hide the latency of a v_fma_f64 behind; the compiler does not interleave them by itself)
+template <int N>
+__device__ __forceinline__ void exp_fast_v(const double (&x)[N], double (&y)[N]) {
+    double n[N], r[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) n[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(n[i], -6.93147180369123816490e-01, x[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(n[i], -1.90821492927058770002e-10, r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = fma_sc(1.0 / 6227020800.0, r[i], 1.0 / 479001600.0);
+#define GPRF_EXP_STEP(c)              \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = fma_sc(p[i], r[i], c);
+    GPRF_EXP_STEP(1.0 / 39916800.0)
+    GPRF_EXP_STEP(1.0 / 3628800.0)
+    GPRF_EXP_STEP(1.0 / 362880.0)
+    GPRF_EXP_STEP(1.0 / 40320.0)
+    GPRF_EXP_STEP(1.0 / 5040.0)
+    GPRF_EXP_STEP(1.0 / 720.0)
+    GPRF_EXP_STEP(1.0 / 120.0)
+    GPRF_EXP_STEP(1.0 / 24.0)
+    GPRF_EXP_STEP(1.0 / 6.0)
+    GPRF_EXP_STEP(0.5)
+    GPRF_EXP_STEP(1.0)
+    GPRF_EXP_STEP(1.0)
+#undef GPRF_EXP_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double v = __builtin_ldexp(p[i], (int)n[i]);
+        y[i] = x[i] < -745.2 ? 0.0 : v;
+    }
+}
+__device__ __forceinline__ double exp_fast(double x) {
+    double xa[1] = {x}, ya[1];
+    exp_fast_v<1>(xa, ya);
+    return ya[0];
+}
+
 // ("euclidean","se"):  r^2 = sum(((a-b)/l)^2),  k = sv exp(-r^2).
 // treegp forms d = sqrt(r^2) with a divide per coordinate and then exp(-d*d); here the scaled differences use the
 // host-rounded reciprocal lengthscales and r^2 goes straight into exp: at most ~2 ulp apart in the exponent's
@@ -85,7 +137,7 @@ struct KernFn<0, 0> {
             double diff = (xi[d] - xj[d]) * p.inv_ls[d];
             sq += diff * diff;
         }
-        return p.sv * exp(-sq);
+        return p.sv * exp_fast(-sq);
     }
     // k, d k(xj, xi)/d xj[d], d k / d ls[t]
     __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
@@ -153,7 +205,7 @@ struct KernFn<1, 1> {
         double dd = (gi[GEO_Z] - gj[GEO_Z]) / p.ls[1];
         double r = sqrt(dk * dk + dd * dd);
         double s3r = SQRT3 * r;
-        return p.sv * (1.0 + s3r) * exp(-s3r);
+        return p.sv * (1.0 + s3r) * exp_fast(-s3r);
     }
     // k(x_i, x_j) with the derivatives with respect to both ends and to the two lengthscales.  The great-circle
     // derivatives are not antisymmetric in the two ends (d a / d lat has the other point's cos(lat) in it), but
@@ -167,7 +219,7 @@ struct KernFn<1, 1> {
         double dd = dz / l1;
         double r = sqrt(dk * dk + dd * dd);
         double s3r = SQRT3 * r;
-        double e = exp(-s3r);
+        double e = exp_fast(-s3r);
         double k = p.sv * (1.0 + s3r) * e;
         double c = -3.0 * p.sv * e;  // dk/dr = c * r ; r cancels against d r/d(.) = (.)/r
         // g * dg/d(lon, lat): dg/da = R / sqrt(a(1-a)); zero at coincident / antipodal points
@@ -718,8 +770,11 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
 // Global traffic is one read of K's upper triangle and one write of U; the per-step chain is
 // substitution + factor with no memory latency in it.
 // ------------------------------------------------------------------------------------------------
-template <int RW, int SLOTS>
-__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT) {
+// GEN: the kernel matrix is not read from the K pool but GENERATED here from the unit's coordinates (SE kernel):
+// k_fill does not run at all, K never exists in HBM, and the prologue's burst of tile loads (every resident unit
+// at once) becomes arithmetic spread over the launch; k_mgrad<.,.,false> re-evaluates the values it needs.
+template <int RW, int SLOTS, bool GEN>
+__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
     extern __shared__ double lds[];
     __shared__ int s_fail;
@@ -793,12 +848,63 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     }
 #define PK(s) __builtin_amdgcn_readlane(pkv, s)
     atile_reserve();
+    // GEN: K(row, col) of this unit, exactly k_fill's definition (identity in the padding, noise + jitter on the
+    // diagonal); the unit's coordinates wait in LDS
+    double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XPAD], GEN only (the launcher sizes the LDS)
+    const double diag_add = kp.nv + ut.jitter[u];
+    // NT tiles (pk = 32 * tile row + tile column) side by side, branch-free: this wave is alone on its SIMD, so the
+    // only thing that hides the latency of one exp()'s dependent chain is the other 4 NT - 1 evaluations
+    auto kgen = [&](auto ntc, const int *pk, double (*out)[4], double sign) {
+        constexpr int NT = decltype(ntc)::value;
+        double sq[NT * 4], e[NT * 4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int col = 16 * (pk[t] & 31) + lr;
+            double xj[3] = {xs[col * XPAD], xs[col * XPAD + 1], xs[col * XPAD + 2]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int row = 16 * (pk[t] >> 5) + 4 * q + lg;
+                double a = 0.0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    double diff = (xs[row * XPAD + d] - xj[d]) * kp.inv_ls[d];      // (unused dimensions: coordinates 0)
+                    a += diff * diff;
+                }
+                sq[4 * t + q] = -a;
+            }
+        }
+        exp_fast_v<NT * 4>(sq, e);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int col = 16 * (pk[t] & 31) + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int row = 16 * (pk[t] >> 5) + 4 * q + lg;
+                double v = kp.sv * e[4 * t + q] + (row == col ? diag_add : 0.0);
+                if (!(row < m && col < m)) v = (row == col) ? 1.0 : 0.0;
+                out[t][q] = sign * v;
+            }
+        }
+    };
+    if constexpr (GEN) {
+        const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
+        for (int e = threadIdx.x; e < mp * XPAD; e += RW * 64) xs[e] = Xu[e];
+        __syncthreads();
+    }
     // diagonal tiles -> LDS
     for (int i = wave; i < T; i += RW) {
+        if constexpr (GEN) {
+            double kv[1][4];
+            int pk[1] = {33 * i};
+            kgen(std::integral_constant<int, 1>{}, pk, kv, 1.0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double *Cs = Kp + (size_t)(16 * i + 4 * q) * mp + 16 * i;
-            Dt[i * 256 + 64 * q + dlane] = Cs[glane];
+            for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = kv[0][q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double *Cs = Kp + (size_t)(16 * i + 4 * q) * mp + 16 * i;
+                Dt[i * 256 + 64 * q + dlane] = Cs[glane];
+            }
         }
     }
 
@@ -839,6 +945,46 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q];
     };
     auto load_tiles = [&]() {
+        if constexpr (GEN) {
+            // tiles -> accumulators, 8 slots at a time: a RUNTIME loop evaluates the batch's tiles into this wave's
+            // quarter of the (still unused) panel buffers — one copy of the exp() code instead of one per slot, which
+            // would not fit the instruction cache — and a static walk moves them into the numbered accumulators
+            double *stage = P0 + wave * (8 * 256);
+            static_for<0, (SLOTS + 7) / 8>([&](auto bc) {
+                constexpr int B0 = 8 * decltype(bc)::value;
+#pragma unroll 1
+                for (int i = 0; i < 8; i += 2) {     // two tiles at a time (a wave's slots are filled from 0 up)
+                    int pk[2] = {(B0 + i < SLOTS) ? __builtin_amdgcn_readlane(pkv, B0 + i) : -1,
+                                 (B0 + i + 1 < SLOTS) ? __builtin_amdgcn_readlane(pkv, B0 + i + 1) : -1};
+                    if (pk[0] >= 0) {                // wave-uniform: only the slots this wave really owns
+                        double kv[2][4];
+                        if (pk[1] >= 0) {
+                            kgen(std::integral_constant<int, 2>{}, pk, kv, -1.0);   // MINUS the trailing tile
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) stage[(i + 1) * 256 + 64 * q + lane] = kv[1][q];
+                        } else {
+                            kgen(std::integral_constant<int, 1>{}, pk, kv, -1.0);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) stage[i * 256 + 64 * q + lane] = kv[0][q];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int S = B0 + decltype(ic)::value;
+                    if constexpr (S < SLOTS) {
+                        if (PK(S) >= 0) {
+                            double kv[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) kv[q] = stage[(S - B0) * 256 + 64 * q + lane];
+                            atile_set<S>(kv);
+                        }
+                    }
+                });
+                __builtin_amdgcn_wave_barrier();
+            });
+            return;
+        }
         // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
         // (volatile) accumulator write, which nothing is moved across
         constexpr int PRO_BATCH = 10;
@@ -1554,7 +1700,9 @@ __device__ __forceinline__ double row16_sum(double v) {
 // DPP row reduction); k values of strictly-lower tiles are read back from the K/U pool, only diagonal tiles
 // re-evaluate exp().  k_gx_finalize folds the per-block partials in a fixed order.
 // ------------------------------------------------------------------------------------------------
-template <int DIST, int KERN>
+// HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
+// (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
+template <int DIST, int KERN, bool HAVEK>
 __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
     int TBm = (ut.max_T + 3) >> 2;
@@ -1748,9 +1896,25 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             for (int d = 0; d < XN; ++d) xj[d] = Xu[(size_t)j * XS + d];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if constexpr (DIST == 0 && KERN == 0)
+                if constexpr (DIST == 0 && KERN == 0 && HAVEK)
                 Kv[q] = diagblk ? Kp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * J + lr]      // diagonal blocks are whole
                                 : Kp[(size_t)(16 * J + lr) * mp + 16 * I + lg + 4 * q];     // K(i,j) = K(j,i)
+            if constexpr (DIST == 0 && KERN == 0 && !HAVEK) {
+                double sq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        double diff = (xi[q][d] - xj[d]) * kp.inv_ls[d];
+                        a += diff * diff;
+                    }
+                    sq[q] = -a;
+                }
+                exp_fast_v<4>(sq, Kv);                  // four chains side by side
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Kv[q] *= kp.sv;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int i = 16 * I + lg + 4 * q;
@@ -1933,7 +2097,7 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
 // granted for (kernel slot, current device)
 static bool lds_needs_optin(int kernel_slot, size_t lds) {
-    static size_t granted[2][64] = {};
+    static size_t granted[3][64] = {};
     if (lds <= 48 * 1024) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
@@ -2068,7 +2232,19 @@ constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGP
 constexpr int POTRF_REG_SLOTS = 32;   // 3 workers x 32 slots >= 14*13/2 strictly-upper tiles (all 256 AGPRs)
 constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 points
 
-void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
+// true when launch_potrf(.., gen_ok = true) will generate the kernel matrices inside k_potrf_reg: every unit of the
+// launch takes the register-resident kernel (SE kernel only).  The caller then skips k_fill and tells k_mgrad.
+static bool potrf_use_reg(const UnitTab &ut) {
+    const char *rg = getenv("GPRF_POTRF_REG");
+    return (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : ut.n_ids <= 4 * device_cus();
+}
+bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
+    const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
+    const bool off = e && e[0] == '0';
+    return !off && dist_id == 0 && kern_id == 0 && ut.n_ids > 0 && ut.max_T <= POTRF_REG_MAXT_C && potrf_use_reg(ut);
+}
+
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s) {
     if (ut.n_ids == 0) return;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
     int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
@@ -2076,19 +2252,26 @@ void launch_potrf(const UnitTab &ut, const Pools &p, hipStream_t s) {
     // launch is a few rounds of workgroups deep (C3: 442 units, 124 vs 145 us), the 2-workgroups-per-CU generic
     // kernel wins on throughput beyond that (C4 on one GPU: 4033 units, 857 vs 914 us).
     // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
-    const int n_cus = device_cus();
-    const char *rg = getenv("GPRF_POTRF_REG");
-    bool use_reg = (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : ut.n_ids <= 4 * n_cus;
+    bool use_reg = potrf_use_reg(ut);
     int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        if (gen && ut.max_T <= reg_maxT) {
+            lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
+            if (lds_needs_optin(2, lds))
+                (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.n_ids),
+                               dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp);
+            return;
+        }
         if (lds_needs_optin(0, lds))
-            (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
+        hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
                            ut, p,
-                           stamps, reg_maxT);
+                           stamps, reg_maxT, kp);
         if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
     }
     size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
@@ -2126,13 +2309,17 @@ void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipSt
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 int total_rows, hipStream_t s) {
+                 int total_rows, bool have_K, hipStream_t s) {
     (void)total_rows;
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     int TBm = (ut.max_T + 3) / 4;
     dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
-    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_mgrad<0, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-    else hipLaunchKernelGGL((k_mgrad<1, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    if (dist_id == 0 && kern_id == 0) {
+        if (have_K) hipLaunchKernelGGL((k_mgrad<0, 0, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        else hipLaunchKernelGGL((k_mgrad<0, 0, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    } else {
+        hipLaunchKernelGGL((k_mgrad<1, 1, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+    }
 }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,

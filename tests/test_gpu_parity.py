@@ -384,3 +384,44 @@ def test_permutation_invariance_and_determinism():
     c = g2.llgrad(grad_X=True)
     assert np.isclose(a[0], c[0], rtol=1e-12) and _close(c[1], a[1], 1e-10)
     g.close(); g2.close()
+
+
+def test_kernel_values_to_a_few_ulp_over_the_whole_exponent_range():
+    """The kernels evaluate exp() with their own routine (range reduction + degree-13 polynomial, see exp_fast in
+    gprf_kernels.hip): the filled K agrees with numpy's exp to 4 ulp from r^2 = 0 down to the subnormals, and is
+    exactly 0 past the underflow threshold."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    m = 64
+    x = np.concatenate([np.linspace(0.0, 1.0, 24), np.linspace(1.0, 27.5, 40)[1:], [31.0]])[:, None]
+    x = x + 0.013 * np.sin(7.0 * np.arange(m))[:, None]            # no special spacing
+    g = GPRF(x, np.zeros((m, 1)), None, GPCov([1.3], [1.0], "euclidean", "se"), 0.25, block_idxs=[np.arange(m)], neighbors=[])
+    g._push_neighbors([])
+    g._ctx.debug_run(np.ascontiguousarray(x), 0)                   # fill only: the K pool
+    K = g._ctx.debug_fetch(0, 0)[:m, :m]
+    d2 = (x - x.T) ** 2
+    ref = 1.3 * np.exp(-d2) + 0.25 * np.eye(m)
+    iu = np.triu_indices(m)
+    assert d2.max() > 800 and np.sum((d2 > 600) & (d2 < 740)) > 5  # the range really is covered
+    normal = ref[iu] > 1e-290
+    assert np.max(np.abs(K[iu][normal] / ref[iu][normal] - 1.0)) < 4 * 2.3e-16
+    assert np.allclose(K[iu][~normal], ref[iu][~normal], rtol=1e-10, atol=1e-322)
+    assert np.all(K[iu][d2[iu] > 746] == 0.0)
+    g.close()
+
+
+def test_generated_and_filled_kernel_matrices_give_the_same_evaluation(monkeypatch):
+    """SE units of up to 256 points: k_potrf_reg generates K itself and k_fill does not run (GPRF_FUSED_FILL=0 forces
+    the K pool back).  Both routes against the golden vectors, and against each other to rounding."""
+    z = load_golden("c1_small.npz")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPRF_FUSED_FILL", mode)
+        g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY")
+        out[mode] = g.llgrad(grad_X=True, grad_cov=True)
+        assert np.isclose(out[mode][0], z["ll_gprf"], rtol=1e-12) and _close(out[mode][1], z["gX_gprf"], 1e-10)
+        # the K pool is written in one mode only
+        g._ctx.debug_run(z["X_obs"], 6)
+        g.close()
+    assert np.isclose(out["1"][0], out["0"][0], rtol=1e-14)
+    assert _close(out["1"][1], out["0"][1], 1e-12) and np.allclose(out["1"][2], out["0"][2], rtol=1e-11)

@@ -38,8 +38,9 @@ def _setting(lines, mangled_part, key):
     raise AssertionError("no .set %s for %s" % (key, mangled_part))
 
 
-def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa):
-    body = _function(isa, "k_potrf_regILi4ELi32")
+@pytest.mark.parametrize("inst", ["k_potrf_regILi4ELi32ELb0E", "k_potrf_regILi4ELi32ELb1E"])   # K read / K generated
+def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa, inst):
+    body = _function(isa, inst)
     inasm, outside, stubs = False, [], 0
     for l in body:
         if "#ASMSTART" in l:
@@ -56,8 +57,8 @@ def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa):
     assert stubs > 300                      # the tile stubs are there (32 tiles x set / get / MFMA)
     assert not outside, outside[:5]         # ... and nothing else names an AGPR
     assert not [l for l in body if "scratch_" in l]          # no spills in the step loop or anywhere else
-    assert _setting(isa, "k_potrf_regILi4ELi32", "num_agpr") == 256
-    assert _setting(isa, "k_potrf_regILi4ELi32", "num_vgpr") <= 256
+    assert _setting(isa, inst, "num_agpr") == 256
+    assert _setting(isa, inst, "num_vgpr") <= 256
 
 
 def test_generic_potrf_does_not_spill(isa):
