@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--task", default="x", choices=["x", "xcov"])
     ap.add_argument("--distinct-x", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-north-star", action="store_true",
+                    help="profiling runs: skip the secondary legs (fill-rate, synchronous, host-inclusive, local-GP, CPU) "
+                         "so that every kernel launch of the process has the north-star shapes")
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="diagnostic: no HIP events between the kernels in the timed region (no roofline then)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -278,16 +281,16 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01d_traffic.json")))
-            key = {"potrf": "k_potrf_reg", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01f_traffic.json")))
+            key = {"potrf": "k_potrf_reg_gen", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 roof["traffic"] = tr[key]["bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                roof["traffic_source"] = "profiles/r01f_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         except Exception:
             pass
         roof["avg_launch_ms"] = stage[dom]
         roof["algorithmic_per_launch"] = fl["fill_bytes"] if dom == "fill" else fl[dom]
-        if world == 1:
+        if world == 1 and not args.only_north_star:
             # K is generated inside k_potrf_reg on this configuration and k_fill does not run; the fill kernel's
             # HBM write rate is measured on the side by forcing the K pool back for a few evaluations
             os.environ["GPRF_FUSED_FILL"] = "0"
@@ -322,7 +325,7 @@ def main():
         }
 
     # ---------------- secondary rates (N = 1 only): synchronous, host-inclusive, local-GP config
-    if world == 1:
+    if world == 1 and not args.only_north_star:
         ev = evs[0]
         ts = []
         for k in range(min(args.steps, 50)):
