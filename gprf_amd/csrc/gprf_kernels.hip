@@ -1705,6 +1705,9 @@ __device__ __forceinline__ double row16_sum(double v) {
 template <int DIST, int KERN, bool HAVEK>
 __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
+    // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
+    // reductions at the end find them in LDS instead of starting with exposed global loads
+    __shared__ double xsh[128 * PtRec<DIST>::NREG];
     int TBm = (ut.max_T + 3) >> 2;
     int slot, bp;
     if (!xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp)) return;
@@ -1726,21 +1729,38 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     const double *__restrict__ W = pl.W + ut.mat_off[u];
     const double *__restrict__ At = pl.At + roff * YPAD;
     int J0 = 4 * JB;
-    int I = 4 * IB + wave;
+    // Which of the block's four row tiles this wave owns rotates with the workgroup: in a diagonal block pair row tile
+    // r has r + 1 column tiles, and wave w of every workgroup sits on SIMD w — unrotated, SIMD 3 would issue four
+    // times the MFMAs of SIMD 0 in all of them at once.
+    const int wrow = (wave + slot + bp) & 3;
+    int I = 4 * IB + wrow;
     bool active = I < T;
     bool diagblk = IB == JB;
     double dyd = (double)kp.dy;
     int nchA = (kp.dy + 15) >> 4;
-    int ks_last = ((kp.dy - 16 * (nchA - 1)) + 3) >> 2;   // k-steps of the last At chunk that hold real rows
     int nchW = T - 4 * IB;
     int nch = nchW + nchA;
 
-    int s_col = tid & 127, s_row0 = tid >> 7;
-    bool s_isJ = s_col >= 64;
-    int scol = s_isJ ? (64 * JB + (s_col - 64)) : (64 * IB + s_col);
-    bool scol_ok = scol < mp && !(diagblk && s_isJ);      // a diagonal block reads its columns once
+    // staging roles, all wave-uniform (scalar row pointers; the only per-lane part of an address is the lane itself):
+    // waves 0/1 carry the even rows of a chunk, waves 2/3 the odd ones; waves 0/2 the I block's 64 columns, waves 1/3
+    // the J block's (nothing for a diagonal block pair, whose columns are staged once)
+    const int s_row0 = wave >> 1;
+    const bool s_isJ = (wave & 1) != 0;
+    const int s_col = 64 * (wave & 1) + lane;
+    const int scol0 = 64 * (s_isJ ? JB : IB);             // first column of this wave's 64
+    const bool s_skip = diagblk && s_isJ;
+    const bool scol_ok = (scol0 + lane) < mp && !s_skip;
     int boff = diagblk ? 0 : 64;                          // where the J columns sit in the staged row
 
+    {
+        constexpr int XS0 = PtRec<DIST>::STRIDE, XN0 = PtRec<DIST>::NREG;
+        const double *Xu0 = pl.Xu + roff * XS0;
+        if (tid < 128) {
+            int p = (tid < 64) ? 64 * IB + tid : 64 * JB + (tid - 64);
+#pragma unroll
+            for (int d = 0; d < XN0; ++d) xsh[tid * XN0 + d] = (p < mp) ? Xu0[(size_t)p * XS0 + d] : 0.0;
+        }
+    }
     d4 acc[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc[jj] = d4{0, 0, 0, 0};
@@ -1749,70 +1769,108 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     for (int jj = 0; jj < 4; ++jj) need[jj] = active && (J0 + jj <= I) && (J0 + jj < T);
 
     double pre0[8], pre1[8];
-    auto src_of = [&](int c) -> const double * {
-        return (c < nchW) ? (W + (size_t)(16 * (4 * IB + c) + s_row0) * mp + scol)
-                          : (At + (size_t)(16 * (c - nchW) + s_row0) * mp + scol);
+    auto src_of = [&](int c) -> const double * {      // scalar: row s_row0 of chunk c, at this wave's first column
+        return (c < nchW) ? (W + (size_t)(16 * (4 * IB + c) + s_row0) * mp + scol0)
+                          : (At + (size_t)(16 * (c - nchW) + s_row0) * mp + scol0);
     };
     auto fetch0 = [&](int c) {
         const double *src = src_of(c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pre0[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+        for (int e = 0; e < 8; ++e) pre0[e] = scol_ok ? src[(size_t)(2 * e) * mp + lane] : 0.0;
     };
     auto fetch1 = [&](int c) {
         const double *src = src_of(c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp] : 0.0;
+        for (int e = 0; e < 8; ++e) pre1[e] = scol_ok ? src[(size_t)(2 * e) * mp + lane] : 0.0;
     };
-    // ks = MFMA k-steps of 4 rows this chunk really has (the last At chunk: rows dy .. are zero padding)
-    auto mma_chunk = [&](const double *buf, double asc, int ks) {
-        const double *rowp = buf + lg * G2_LD + lr;
-        double a[4];
+    // need[] is a prefix (both of its conditions are monotone in jj): njj tiles.  The B operands of tile jj + 1 are
+    // read from LDS before tile jj's MFMAs issue (left to itself the compiler emits read -> wait -> 2 MFMAs twice per
+    // tile: two exposed LDS round trips per 256 cycles of MFMA).
+    int njj = 0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = asc * rowp[(4 * s) * G2_LD + 16 * wave];
+    for (int jj = 0; jj < 4; ++jj) njj += need[jj] ? 1 : 0;
+    auto mma_chunk = [&](const double *buf, double asc) {
+        const double *rowp = buf + lg * G2_LD + lr;
+        double a[4], b[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = rowp[(4 * s) * G2_LD + 16 * wrow];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[0][s] = rowp[(4 * s) * G2_LD + boff];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] *= asc;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            if (need[jj]) {
-                double b[4];
+            if (jj < njj) {
+                if (jj + 1 < 4 && jj + 1 < njj) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[s] = rowp[(4 * s) * G2_LD + boff + 16 * jj];
+                    for (int s = 0; s < 4; ++s) b[(jj + 1) & 1][s] = rowp[(4 * s) * G2_LD + boff + 16 * (jj + 1)];
+                }
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s < ks) acc[jj] = mfma(a[s], b[s], acc[jj]);
+                for (int s = 0; s < 4; ++s) acc[jj] = mfma(a[s], b[jj & 1][s], acc[jj]);
             }
         }
     };
+#ifdef GPRF_MGRAD_FINE
+    unsigned long long tstep[3] = {0, 0, 0}, tsp = 0;      // [write + barrier | fetch issue | MFMAs]
+#define GPRF_SST2(k) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tstep[k] += tn - tsp; tsp = tn; }
+#else
+#define GPRF_SST2(k)
+#endif
     auto step = [&](int c, double (&pre)[8], bool refill_even) {
+#ifdef GPRF_MGRAD_FINE
+        tsp = __builtin_amdgcn_s_memtime();
+#endif
         double *buf = chunk[c & 1];
-        if (!(diagblk && s_isJ)) {
+        if (!s_skip) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) buf[(2 * e + s_row0) * G2_LD + s_col] = pre[e];
         }
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for chunk c+1's loads, which were
+        // issued one step ago precisely so that they need NOT be back yet
+        lds_barrier();
+        GPRF_SST2(0)
         if (c + 2 < nch) { if (refill_even) fetch0(c + 2); else fetch1(c + 2); }
+        GPRF_SST2(1)
         // the -dy of the W part rides on the A operand (4 multiplies per chunk): the accumulators are never
         // rescaled in the middle of the chunk loop
 #ifndef GPRF_ABL_MG_NOMMA
         if (c < nchW) {
-            if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd, 4);
+            if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd);
         } else {
-            if (active) mma_chunk(buf, 1.0, (c == nch - 1) ? ks_last : 4);
+            if (active) mma_chunk(buf, 1.0);       // (the last chunk's rows beyond dy are zero padding)
         }
 #endif
+        GPRF_SST2(2)
     };
+#ifdef GPRF_PROFILE
+    // diagnostic build: cycles of [prologue | chunk loop | reductions] of the unit's first (diagonal, longest) and last
+    // (bottom-left) block pair -> Pools::dbg[u][0..3] / [4..7]
+    unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
     fetch0(0);
     if (nch > 1) fetch1(1);
+#ifdef GPRF_PROFILE
+    unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = 0; c < nch; c += 2) {
         step(c, pre0, true);
         if (c + 1 < nch) step(c + 1, pre1, false);
     }
+#ifdef GPRF_PROFILE
+    unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+    unsigned long long tme[4] = {0, 0, 0, 0};
+#define GPRF_MST(k) tme[k] = __builtin_amdgcn_s_memtime();
+#else
+#define GPRF_MST(k)
+#endif
     // ---- the block pair's M tiles are in the accumulators (lane (lg, lr), acc[jj][q] = M[16 I + lg + 4q][16 (J0+jj)
     //      + lr]); reduce them against dk/dx and dk/dtheta right here: M never goes to memory ----
     __syncthreads();                                   // the staging buffer is reused for the reductions
+    GPRF_MST(0)
     double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
     double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
     const double *__restrict__ Kp = pl.K + ut.mat_off[u];
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
-    const double *__restrict__ Xu = pl.Xu + roff * XS;
     const int tbs = TBm;                               // stride of the per-block partials
     double rowsum[4][3], xi[4][XN];
 #pragma unroll
@@ -1821,7 +1879,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
 #pragma unroll
         for (int d = 0; d < 3; ++d) rowsum[q][d] = 0.0;
 #pragma unroll
-        for (int d = 0; d < XN; ++d) xi[q][d] = active ? Xu[(size_t)i * XS + d] : 0.0;
+        for (int d = 0; d < XN; ++d) xi[q][d] = xsh[(16 * wrow + lg + 4 * q) * XN + d];
+        (void)i;
     }
     double gc_tr = 0.0, gc_sv = 0.0, gc_l[3] = {0.0, 0.0, 0.0};
     double csum[4][3];
@@ -1834,7 +1893,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         fx[d] = used ? -2.0 / (kp.ls[d] * kp.ls[d]) : 0.0;
         fl[d] = used ? 2.0 / (kp.ls[d] * kp.ls[d] * kp.ls[d]) : 0.0;
     }
-    // the wave's diagonal tile (diagonal block pairs only; it is tile jj == wave): k re-evaluated from the
+    // the wave's diagonal tile (diagonal block pairs only; it is tile jj == wrow): k re-evaluated from the
     // coordinates (the pool holds U there), column sums only
     double csd[3] = {0.0, 0.0, 0.0};
 #ifdef GPRF_ABL_MG_NOEPI
@@ -1843,11 +1902,11 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     constexpr bool epi = true;
 #endif
     if (epi && active && diagblk) {                    // wave-uniform
-        d4 md = wave == 0 ? acc[0] : (wave == 1 ? acc[1] : (wave == 2 ? acc[2] : acc[3]));
+        d4 md = wrow == 0 ? acc[0] : (wrow == 1 ? acc[1] : (wrow == 2 ? acc[2] : acc[3]));
         int j = 16 * I + lr;
         double xj[XN];
 #pragma unroll
-        for (int d = 0; d < XN; ++d) xj[d] = Xu[(size_t)j * XS + d];
+        for (int d = 0; d < XN; ++d) xj[d] = xsh[(16 * wrow + lr) * XN + d];      // diagonal block: J block = I block
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = 16 * I + lg + 4 * q;
@@ -1881,19 +1940,20 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             }
         }
     }
+    GPRF_MST(1)
     // strictly-lower tiles: k read back from the K pool, which holds the 64x64 blocks JB <= IB only: transposed
     // access for an off-diagonal block pair (the four q-loads of a lane cover one 128-byte line);
     // column sums for the points of J, row sums for the points of I, everything counted twice in the theta sums
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        bool mydiag = diagblk && jj == wave;
+        bool mydiag = diagblk && jj == wrow;
         double colsum[3] = {mydiag ? csd[0] : 0.0, mydiag ? csd[1] : 0.0, mydiag ? csd[2] : 0.0};
         if (epi && need[jj] && J0 + jj < I) {          // wave-uniform
             int J = J0 + jj;
             int j = 16 * J + lr;
             double xj[XN], Kv[4];
 #pragma unroll
-            for (int d = 0; d < XN; ++d) xj[d] = Xu[(size_t)j * XS + d];
+            for (int d = 0; d < XN; ++d) xj[d] = xsh[(64 + 16 * jj + lr) * XN + d];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if constexpr (DIST == 0 && KERN == 0 && HAVEK)
@@ -1957,6 +2017,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             csum[jj][d] = v;
         }
     }
+    GPRF_MST(2)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -1992,6 +2053,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
 #pragma unroll
         for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
     }
+    GPRF_MST(3)
     __syncthreads();
     {
         // column partial of this block pair: colpart[column j of block JB][IB]
@@ -2003,6 +2065,31 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             pl.colpart[((roff + j) * tbs + IB) * XPAD + d] = v;
         }
     }
+#ifdef GPRF_PROFILE
+#ifndef GPRF_MGRAD_FINE
+    if (tid == 0 && (bp == 0 || (JB == 0 && IB == TB - 1 && TB > 1))) {
+        unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+        double *dg = pl.dbg + (size_t)u * 8 + (bp == 0 ? 0 : 4);
+        dg[0] = (double)(tm1 - tm0); dg[1] = (double)(tm2 - tm1); dg[2] = (double)(tm3 - tm2); dg[3] = (double)nch;
+    }
+#endif
+#ifdef GPRF_MGRAD_FINE
+    // the reductions split [barrier | diagonal tile | lower tiles | row sums, theta sums | last barrier + stores], then
+    // the chunk loop and its length; bottom-left pair only (overwrites the record above)
+    if (tid == 0 && JB == 0 && IB == TB - 1) {
+        double *dg = pl.dbg + (size_t)u * 8;
+        unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+        dg[0] = (double)(tme[0] - tm2); dg[1] = (double)(tme[1] - tme[0]); dg[2] = (double)(tme[2] - tme[1]);
+        dg[3] = (double)(tme[3] - tme[2]); dg[4] = (double)(tm3 - tme[3]); dg[5] = (double)(tm2 - tm1); dg[6] = (double)nch;
+#ifdef GPRF_MGRAD_LOOP      // ... or the chunk loop split [LDS write + barrier | fetch issue | MFMAs] in slots 0..2
+        dg[0] = (double)tstep[0]; dg[1] = (double)tstep[1]; dg[2] = (double)tstep[2];
+#endif
+    }
+#else
+    (void)tme;
+#endif
+#endif
+#undef GPRF_MST
     if (tid < GC_SLOTS) {
         double v = 0.0;
         if (tid < 5) v = gcred[0][tid] + gcred[1][tid] + gcred[2][tid] + gcred[3][tid];
