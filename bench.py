@@ -121,13 +121,21 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook for 1-GPU boxes: GPRF_BENCH_ONE_GPU=1 lets N ranks time-share GPU 0 with gloo collectives, so that the
+    # multi-rank code path of this file can be exercised end to end; the numbers of such a run mean nothing
+    one_gpu = os.environ.get("GPRF_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1":   # the latter: exercise the RCCL path on one GPU
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gprf_amd import grid_centers, _capi
     from gprf_amd import dist as gdist
@@ -319,6 +327,7 @@ def main():
                                       args.nblocks, len(sd.neighbors) if args.local_dist < 1.0 else 0, args.task),
                        "distinct_X": nX, "parallelism": "units sharded over %d rank(s), 1 all-reduce/eval" % world},
             "roofline": roof,
+            **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks time-share one GPU over gloo; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
             "stage_timing": "HIP events between the kernels on every %d-th evaluation of the timed region (%d sampled)"
                             % (TIMING_PERIOD, cnt),

@@ -1,0 +1,33 @@
+"""bench.py's multi-rank code path end to end on a one-GPU box: two ranks time-share GPU 0 (GPRF_BENCH_ONE_GPU=1, gloo
+collectives instead of RCCL).  Checks the contract of the JSON line, not its numbers."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_prints_one_contract_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GPRF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "14", "--warmup", "2",
+           "--ntrain", "2000", "--nblocks", "16", "--yd", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["steps"] == 14 and d["warmup"] == 2 and d["value"] > 0
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9
+    assert "not a measurement" in d["note"] and d["roofline"]["frac"] > 0
