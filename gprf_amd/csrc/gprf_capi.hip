@@ -89,9 +89,10 @@ struct gprf_ctx {
     DevBuf<double> d_X, d_Y, d_out;
     // tables: views into the single staged table buffer d_tab (see rebuild_units)
     template <typename T> struct View { T *p = nullptr; void release() { p = nullptr; } };
-    View<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_row_unit, d_ids;
+    View<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_ids;
+    DevBuf<int32_t> d_row_unit;           // filled on the device (k_row_unit)
     View<int64_t> d_matoff, d_slot_ptr;
-    View<double> d_weight, d_jitter, d_slot_w;
+    View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
     DevBuf<int32_t> d_info;
@@ -244,11 +245,6 @@ int rebuild_units(gprf_ctx *c) {
 
     // unit row -> point table and the point -> slots CSR for the deterministic gather (gprf.py:258-273)
     std::vector<int32_t> upt((size_t)rows, -1);
-    std::vector<int32_t> row_unit((size_t)rows, 0);
-    for (int l = 0; l < nl; ++l) {
-        int mp = pad16(c->l_m[l]);
-        std::fill(row_unit.begin() + c->l_rowoff[l], row_unit.begin() + c->l_rowoff[l] + mp, l);
-    }
     std::vector<int64_t> slot_cnt((size_t)c->n + 1, 0);
     for (int l = 0; l < nl; ++l) {
         int u = c->l_global[l];
@@ -270,7 +266,6 @@ int rebuild_units(gprf_ctx *c) {
     std::vector<int64_t> slot_ptr((size_t)c->n + 1, 0);
     for (int p = 0; p < c->n; ++p) slot_ptr[p + 1] = slot_ptr[p] + slot_cnt[p + 1];
     std::vector<int32_t> slot_row((size_t)slot_ptr[c->n]);
-    std::vector<double> slot_w((size_t)slot_ptr[c->n]);
     {
         std::vector<int64_t> cur(slot_ptr.begin(), slot_ptr.end() - 1);
         for (int l = 0; l < nl; ++l) {
@@ -278,7 +273,6 @@ int rebuild_units(gprf_ctx *c) {
             for (int r = 0; r < c->l_m[l]; ++r) {
                 int64_t k = cur[src[r]]++;
                 slot_row[k] = c->l_rowoff[l] + r;
-                slot_w[k] = weight[l];
             }
         }
     }
@@ -328,6 +322,7 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1));
     HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1));
     HIP_TRY(c, c->d_gXu.reserve((size_t)rows * XPAD + 1));
+    HIP_TRY(c, c->d_row_unit.reserve((size_t)rows + 1));
 
     // ONE staged upload: every table is packed (256-byte aligned) into one pinned buffer and copied with a
     // single asynchronous H2D on the context stream (ten small synchronous copies cost ~0.25 ms per re-blocking)
@@ -342,10 +337,8 @@ int rebuild_units(gprf_ctx *c) {
             {weight.data(), (size_t)nl * sizeof(double), (void **)&c->d_weight.p},
             {jitter.data(), (size_t)nl * sizeof(double), (void **)&c->d_jitter.p},
             {upt.data(), (size_t)rows * sizeof(int32_t), (void **)&c->d_upt.p},
-            {row_unit.data(), (size_t)rows * sizeof(int32_t), (void **)&c->d_row_unit.p},
             {slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), (void **)&c->d_slot_ptr.p},
             {slot_row.data(), slot_row.size() * sizeof(int32_t), (void **)&c->d_slot_row.p},
-            {slot_w.data(), slot_w.size() * sizeof(double), (void **)&c->d_slot_w.p},
         };
         size_t total = 0;
         for (auto &sg : segs) total += (sg.bytes + 255) & ~(size_t)255;
@@ -363,6 +356,7 @@ int rebuild_units(gprf_ctx *c) {
     // Y rows of every unit (Y never changes; membership does)
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
+    launch_row_unit(ut, c->d_row_unit.p, s);
     launch_gather_y(ut, pl, c->d_Y.p, c->dy, (int)rows, s);
     HIP_TRY(c, hipGetLastError());
     // an evaluation enqueued on a caller's stream waits for this event instead of a host sync (enqueue_eval)
@@ -405,7 +399,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
     KParams kp = make_kparams(c);
-    AssembleTab at{c->d_slot_ptr.p, c->d_slot_row.p, c->d_slot_w.p};
+    AssembleTab at{c->d_slot_ptr.p, c->d_slot_row.p};
     bool tm = c->timing;
     if (tm && !c->ev_valid) {
         for (int r = 0; r < gprf_ctx::RING; ++r)
@@ -541,7 +535,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_m.release(); c->d_rowoff.release();
     c->d_upt.release(); c->d_slot_row.release(); c->d_info.release(); c->d_matoff.release();
-    c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release(); c->d_slot_w.release();
+    c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release();
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();

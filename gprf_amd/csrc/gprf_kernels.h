@@ -30,7 +30,7 @@ struct UnitTab {
     const double *weight;    // Bethe weight: 1 - deg(i) for unaries, 1 for pairs
     const double *jitter;    // extra diagonal (jitchol retry)
     const int32_t *upt;      // [total padded rows] global point index of each unit row, -1 for padding
-    const int32_t *row_unit; // [total padded rows] local unit id of each padded row
+    const int32_t *row_unit; // [total padded rows] local unit id of each padded row (filled on the device: k_row_unit)
     const int32_t *ids;      // the local unit ids this launch covers (one stream group) ...
     int n_ids;               // ... and how many
     int n_units;
@@ -60,13 +60,13 @@ struct Pools {
 
 struct AssembleTab {
     const int64_t *slot_ptr;   // [n+1]
-    const int32_t *slot_row;   // padded-row index into gXu
-    const double *slot_w;      // unit weight
+    const int32_t *slot_row;   // padded-row index into gXu (the slot's weight is its unit's: weight[row_unit[row]])
 };
 
 void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
                   int32_t *block_of, int32_t *changed, hipStream_t s);
+void launch_row_unit(const UnitTab &ut, int32_t *row_unit, hipStream_t s);
 void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
 void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
