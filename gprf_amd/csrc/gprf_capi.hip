@@ -313,9 +313,9 @@ int rebuild_units(gprf_ctx *c) {
     HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
     HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1));
     HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1));
-    HIP_TRY(c, c->d_K.reserve((size_t)mat + 1));
-    HIP_TRY(c, c->d_U.reserve((size_t)mat + 1));
-    HIP_TRY(c, c->d_W.reserve((size_t)mat + 1));
+    HIP_TRY(c, c->d_K.reserve((size_t)mat + GPRF_POOL_SLACK));
+    HIP_TRY(c, c->d_U.reserve((size_t)mat + GPRF_POOL_SLACK));
+    HIP_TRY(c, c->d_W.reserve((size_t)mat + GPRF_POOL_SLACK));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
     HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1));      // XPAD, or 8 for the lld record
     HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));

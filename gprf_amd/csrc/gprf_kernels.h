@@ -37,6 +37,10 @@ struct UnitTab {
     int max_T;               // max over units of mp/16
 };
 
+// spare doubles behind the last unit's matrix in the U / W / K pools: k_solve_panel's row-panel loads run up to
+// 64 * 7 columns wide regardless of the unit's edge
+constexpr size_t GPRF_POOL_SLACK = 512;
+
 struct Pools {
     double *K;     // kernel matrices, row-major mp x mp per unit: k_fill writes the 64x64 blocks ti <= tj only
                    // (diagonal blocks whole); read by the Cholesky once and by k_mgrad

@@ -1439,14 +1439,18 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     });
     // staging registers: wave w carries rows 4w..4w+3 of the panel, NCH column chunks of 64, plus one V entry
     double pre[4][NCH], prev;
+    // scalar row base + lane offset + immediate (no VALU address arithmetic per load); lanes left of the diagonal tile
+    // or right of mp load nothing (the kernel is HBM-bound: unpredicated loads cost 15 % more time)
     auto fetch = [&](int r) {
-        const double *Ur = U + (size_t)(16 * r + 4 * wave) * mp;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             int col = 64 * k + lane;
             bool ok = col >= 16 * (r + 1) && col < mp;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) pre[rr][k] = ok ? Ur[(size_t)rr * mp + col] : 0.0;
+            for (int rr = 0; rr < 4; ++rr) {
+                const double *Ur = U + (size_t)(16 * r + 4 * wave + rr) * mp;      // wave-uniform
+                pre[rr][k] = ok ? Ur[64 * k + (unsigned)lane] : 0.0;
+            }
         }
         prev = V[(size_t)r * 256 + tid];
     };
