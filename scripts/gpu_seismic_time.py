@@ -1,6 +1,6 @@
 """Stage timing of the seismic configuration (BASELINE config 5's shape: great-circle/depth distance, Matern-3/2,
 tree blocks of < 210 events, edge threshold 0.6, task xcov) on the stand-in catalogue:
-    python scripts/gpu_seismic_time.py [n] [reps]        (ORACLE=1 also times the CPU restatement once)"""
+    python scripts/gpu_seismic_time.py [n] [reps]        (comparison with the oracle: tests/diag/gpu_seismic_diag.py)"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,16 +33,6 @@ def main(n=20000, reps=20, yd=50, blocksize=210, threshold=0.6, lscale=40.0):
     st = g._ctx.get_timing()
     print("stages(us)", {k: round(v * 1e3, 1) for k, v in st.items() if k != "count"})
     g._ctx.set_timing(False, reset=True)
-    if os.environ.get("ORACLE"):
-        from oracle.gprf_ref import GPRFRef
-        from oracle.vector_tree import GPCov as OC
-        r = GPRFRef(X, Y, None, OC([1.0], [lscale, lscale], "lld", "matern32"), 0.1, block_idxs=g.block_idxs,
-                    neighbors=g.neighbors)
-        t = time.time(); a = r.llgrad(grad_X=True, grad_cov=True); tc = time.time() - t
-        b = g.llgrad(grad_X=True, grad_cov=True)
-        print("oracle (CPU restatement) one eval: %.1f s; ll rel diff %.2e, gX max-abs diff / max %.2e, gC rel %.2e"
-              % (tc, abs(a[0] - b[0]) / abs(a[0]), np.max(np.abs(a[1] - b[1])) / np.max(np.abs(a[1])),
-                 np.max(np.abs(a[2] - b[2]) / np.abs(a[2]))))
     # the optimiser's view: callback with re-routing through the tree
     obj = seismic.SeismicObjective(g, X, np.array([[0.1, 1.0, lscale, lscale]]), x_prior=seismic.make_x_prior(X, 2.0))
     x = obj.full0.copy()

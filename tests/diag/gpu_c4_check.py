@@ -3,7 +3,7 @@ random-normal Y (the N=80500 prior draw is out of reach of the reference's own d
 path runs at that size, times it, and spot-checks two units against the oracle."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gprf_amd import GPCov, Blocker, grid_centers
 from gprf_amd.gprf import GPRF
 rng = np.random.RandomState(2)

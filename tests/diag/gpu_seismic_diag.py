@@ -1,7 +1,7 @@
-"""Where does the seismic configuration leave the oracle?  python scripts/gpu_seismic_diag.py"""
+"""Where does the seismic configuration leave the oracle?  python tests/diag/gpu_seismic_diag.py"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gprf_amd import GPCov, seismic
 from gprf_amd.gprf import GPRF
 from oracle.gprf_ref import GPRFRef
@@ -35,3 +35,5 @@ case(4000, 210, "lld", "matern32", [40.0, 40.0], 0.6)
 case(4000, 400, "lld", "matern32", [40.0, 40.0], 0.6)
 case(4000, 400, "lld", "matern32", [40.0, 40.0], 0.6, local=True)
 case(8000, 210, "lld", "matern32", [40.0, 40.0], 0.6)
+if os.environ.get("BIG"):      # BASELINE config 5's shape, the oracle takes ~40 s
+    case(20000, 210, "lld", "matern32", [40.0, 40.0], 0.6, yd=50)

@@ -1,8 +1,8 @@
 """GPU bring-up: per-stage comparison of the HIP pipeline against numpy + the oracle on small problems.
-Run on a GPU box:  python scripts/gpu_stage_check.py"""
+Run on a GPU box:  python tests/diag/gpu_stage_check.py"""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gprf_amd import _capi, GPCov, Blocker, grid_centers
 from gprf_amd.gprf import GPRF
 from oracle.gprf_ref import GPRFRef
