@@ -8,6 +8,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/gprf_hip.h"
@@ -91,6 +92,8 @@ struct gprf_ctx {
     template <typename T> struct View { T *p = nullptr; void release() { p = nullptr; } };
     View<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_ids;
     DevBuf<int32_t> d_row_unit;           // filled on the device (k_row_unit)
+    std::vector<int32_t> w_upt, w_slot_row, w_pcnt;   // rebuild_units scratch (kept: no allocation per re-blocking)
+    std::vector<int64_t> w_slot_ptr;
     View<int64_t> d_matoff, d_slot_ptr;
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
@@ -191,6 +194,15 @@ KParams make_kparams(gprf_ctx *c) {
 // (Re)build the local unit tables after blocks / neighbours / shard / jitter changed.
 // Units: blocks 0..n_blocks-1 (gprf.py:236), then pairs in the caller's order (gprf.py:239).
 int rebuild_units(gprf_ctx *c) {
+    static const bool rb_timing = [] { const char *e = getenv("GPRF_REBUILD_TIMING"); return e && e[0] == '1'; }();
+    auto rb_now = [] { return std::chrono::steady_clock::now(); };
+    auto rb_t0 = rb_now();
+    auto rb_lap = [&](const char *what) {
+        if (!rb_timing) return;
+        auto t = rb_now();
+        fprintf(stderr, "[rebuild] %-18s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - rb_t0).count());
+        rb_t0 = t;
+    };
     const int nb = c->n_blocks, np = c->n_pairs;
     const int nu = nb + np;
     std::vector<int32_t> um(nu);
@@ -243,40 +255,53 @@ int rebuild_units(gprf_ctx *c) {
     c->work_flops = flops;
     c->work_fill_bytes = fbytes;
 
+    rb_lap("units + shard");
     // unit row -> point table and the point -> slots CSR for the deterministic gather (gprf.py:258-273)
-    std::vector<int32_t> upt((size_t)rows, -1);
-    std::vector<int64_t> slot_cnt((size_t)c->n + 1, 0);
+    // Every point sits in exactly one block, so its slots are its block's local units in ascending unit order: counts
+    // and ranks are kept per BLOCK, the row tables are block-wise copies, and the only per-row work left is the scatter
+    // of the slot rows.  (Scratch vectors live in the context: no allocation per re-blocking.)
+    std::vector<int32_t> &upt = c->w_upt;
+    std::vector<int64_t> &slot_ptr = c->w_slot_ptr;
+    std::vector<int32_t> &slot_row = c->w_slot_row;
+    std::vector<int32_t> &pcnt = c->w_pcnt;
+    upt.resize((size_t)rows);
+    std::vector<int32_t> bcnt((size_t)nb, 0), brank((size_t)nb, 0);
+    for (int l = 0; l < nl; ++l) {
+        int u = c->l_global[l];
+        if (u < nb) bcnt[u]++;
+        else { bcnt[c->pairs[2 * (u - nb)]]++; bcnt[c->pairs[2 * (u - nb) + 1]]++; }
+    }
+    pcnt.assign((size_t)c->n, 0);
+    for (int b = 0; b < nb; ++b)
+        for (int64_t k = c->block_ptr[b]; k < c->block_ptr[b + 1]; ++k) pcnt[c->block_pts[k]] += bcnt[b];
+    slot_ptr.resize((size_t)c->n + 1);
+    slot_ptr[0] = 0;
+    for (int p = 0; p < c->n; ++p) slot_ptr[p + 1] = slot_ptr[p] + pcnt[p];
+    slot_row.resize((size_t)slot_ptr[c->n]);
     for (int l = 0; l < nl; ++l) {
         int u = c->l_global[l];
         int32_t *dst = upt.data() + c->l_rowoff[l];
-        auto copy_block = [&](int b, int32_t *d) {
+        auto place = [&](int b, int off) {
             int64_t s = c->block_ptr[b], e = c->block_ptr[b + 1];
-            for (int64_t k = s; k < e; ++k) d[k - s] = c->block_pts[k];
-            return (int)(e - s);
+            const int32_t *pts = c->block_pts.data() + s;
+            int cnt = (int)(e - s);
+            if (cnt) memcpy(dst + off, pts, (size_t)cnt * sizeof(int32_t));
+            int rk = brank[b]++;
+            int32_t base = c->l_rowoff[l] + off;
+            for (int k = 0; k < cnt; ++k) slot_row[slot_ptr[pts[k]] + rk] = base + k;
+            return cnt;
         };
+        int mfill;
         if (u < nb) {
-            copy_block(u, dst);
+            mfill = place(u, 0);
         } else {
-            int i = c->pairs[2 * (u - nb)], j = c->pairs[2 * (u - nb) + 1];
-            int ni = copy_block(i, dst);
-            copy_block(j, dst + ni);
+            int ni = place(c->pairs[2 * (u - nb)], 0);
+            mfill = ni + place(c->pairs[2 * (u - nb) + 1], ni);
         }
-        for (int r = 0; r < c->l_m[l]; ++r) slot_cnt[dst[r] + 1]++;
+        int mp = pad16(c->l_m[l]);
+        for (int r = mfill; r < mp; ++r) dst[r] = -1;
     }
-    std::vector<int64_t> slot_ptr((size_t)c->n + 1, 0);
-    for (int p = 0; p < c->n; ++p) slot_ptr[p + 1] = slot_ptr[p] + slot_cnt[p + 1];
-    std::vector<int32_t> slot_row((size_t)slot_ptr[c->n]);
-    {
-        std::vector<int64_t> cur(slot_ptr.begin(), slot_ptr.end() - 1);
-        for (int l = 0; l < nl; ++l) {
-            const int32_t *src = upt.data() + c->l_rowoff[l];
-            for (int r = 0; r < c->l_m[l]; ++r) {
-                int64_t k = cur[src[r]]++;
-                slot_row[k] = c->l_rowoff[l] + r;
-            }
-        }
-    }
-
+    rb_lap("upt + slots");
     // unit id lists: group g = every n_groups-th unit in descending-cost order (group 0 when n_groups == 1
     // is simply all units, largest first, so that the long factorizations start first)
     std::vector<int32_t> ids(nl);
@@ -301,6 +326,7 @@ int rebuild_units(gprf_ctx *c) {
         for (int gg = g + 1; gg <= gprf_ctx::MAX_GROUPS; ++gg) c->group_begin[gg] = nl;
     }
 
+    rb_lap("order + groups");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     size_t nl1 = (size_t)std::max(nl, 1);
@@ -326,7 +352,9 @@ int rebuild_units(gprf_ctx *c) {
 
     // ONE staged upload: every table is packed (256-byte aligned) into one pinned buffer and copied with a
     // single asynchronous H2D on the context stream (ten small synchronous copies cost ~0.25 ms per re-blocking)
+    rb_lap("reserve");
     HIP_TRY(c, hipStreamSynchronize(s));     // the previous staging buffer / tables may still be in use
+    rb_lap("stream sync");
     {
         struct Seg { const void *src; size_t bytes; void **dst; };
         Seg segs[] = {
@@ -353,6 +381,7 @@ int rebuild_units(gprf_ctx *c) {
         }
         HIP_TRY(c, hipMemcpyAsync(c->d_tab.p, c->h_tab.p, off, hipMemcpyHostToDevice, s));
     }
+    rb_lap("pack + H2D enqueue");
     // Y rows of every unit (Y never changes; membership does)
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
@@ -362,6 +391,7 @@ int rebuild_units(gprf_ctx *c) {
     // an evaluation enqueued on a caller's stream waits for this event instead of a host sync (enqueue_eval)
     if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_tables, s));
+    rb_lap("launches");
     c->units_dirty = false;
     return GPRF_OK;
 }
