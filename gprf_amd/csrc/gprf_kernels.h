@@ -37,8 +37,8 @@ struct UnitTab {
     int max_T;               // max over units of mp/16
 };
 
-// spare doubles behind the last unit's matrix in the U / W / K pools: k_solve_panel's row-panel loads run up to
-// 64 * 7 columns wide regardless of the unit's edge
+// spare doubles behind the last unit's matrix in the U / W / K pools (row-panel loads address whole 64-column
+// chunks; the lanes beyond the unit's edge are masked off, the slack keeps even an unmasked variant in bounds)
 constexpr size_t GPRF_POOL_SLACK = 512;
 
 struct Pools {

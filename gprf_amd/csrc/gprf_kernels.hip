@@ -1695,14 +1695,15 @@ __device__ __forceinline__ double row16_sum(double v) {
 // k_mgrad: one workgroup per 64x64 block pair (IB >= JB) of one unit.
 // MFMA half: M_IJ = At_I^T At_J - dy sum_k W_kI^T W_kJ for its (up to) 16 lower-triangle tiles: 16-row chunks of
 // the stacked operand [W ; At] (both row-major, leading dimension mp) are staged in LDS (two register sets keep
-// chunks c+1 and c+2 in flight, one barrier per chunk; diagonal blocks stage their 64 columns once); wave w owns
-// row tile I = 4 IB + w against the four J tiles (1 A read + 4 B reads per 4 MFMAs); the W chunks come first,
-// the accumulators are then scaled by -dy and the At chunks continue in the same registers.
+// chunks c+1 and c+2 in flight, one LDS-only barrier per chunk; diagonal blocks stage their 64 columns once); a wave
+// owns one row tile I of the block (which one rotates with the workgroup) against the four J tiles: the A operands
+// are read once per chunk, the B operands of tile jj + 1 before tile jj's four MFMAs; the W chunks come first with
+// -dy riding on their A operands, the At chunks continue in the same accumulators.
 // Reduction half: the accumulator layout is exactly what the reduction wants (a lane holds 4 rows of one
 // column), so the tiles are reduced in place against dk/dx, dk/dtheta — M is never written.  A strictly-lower
 // tile gives column sums to the points of J (-> colpart[j][IB]) and row sums to the points of I (-> rowpart[i][JB],
-// DPP row reduction); k values of strictly-lower tiles are read back from the K/U pool, only diagonal tiles
-// re-evaluate exp().  k_gx_finalize folds the per-block partials in a fixed order.
+// DPP row reduction); the points' coordinates wait in LDS since kernel start.  k_gx_finalize folds the per-block
+// partials in a fixed order.
 // ------------------------------------------------------------------------------------------------
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
