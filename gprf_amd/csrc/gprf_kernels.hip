@@ -2404,7 +2404,10 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     // single-unit latency matters while the launch is about one workgroup-round deep (sharded runs); beyond
     // that the wide form's operand reuse wins (C3 on one GPU: 55 vs 58 us, C4: 324 vs 429 us)
-    if (ut.n_ids <= device_cus())
+    // GPRF_AT_WIDE=0 / 1 forces one or the other (diagnostics)
+    const char *aw = getenv("GPRF_AT_WIDE");
+    bool wide = (aw && (aw[0] == '0' || aw[0] == '1')) ? aw[0] == '1' : ut.n_ids > device_cus();
+    if (!wide)
         hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
     else
         hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
