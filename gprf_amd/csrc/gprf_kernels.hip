@@ -1707,8 +1707,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
-template <int DIST, int KERN, bool HAVEK>
-__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
+template <int DIST, int KERN, bool HAVEK, bool FAST>
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
     // reductions at the end find them in LDS instead of starting with exposed global loads
@@ -1877,6 +1877,11 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
     const double *__restrict__ Kp = pl.K + ut.mat_off[u];
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
     const int tbs = TBm;                               // stride of the per-block partials
+    // FAST instantiation (SE kernel, at most two input dimensions, no hyper-parameter gradient — the north-star
+    // task): the third coordinate's terms and the theta sums are compiled out of the reductions, whose VALU volume
+    // is what bounds this kernel
+    constexpr int ND = FAST ? 2 : 3;
+    constexpr bool GC = !FAST;
     double rowsum[4][3], xi[4][XN];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1919,14 +1924,16 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             double Mij = ok ? md[q] : 0.0;
             if constexpr (DIST == 0 && KERN == 0) {
                 double g = Mij * KernFn<0, 0>::value(kp, xi[q], xj);
-                gc_tr += (i == j) ? Mij : 0.0;
-                gc_sv += g;
+                if constexpr (GC) {
+                    gc_tr += (i == j) ? Mij : 0.0;
+                    gc_sv += g;
+                }
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
+                for (int d = 0; d < ND; ++d) {
                     double delta = xj[d] - xi[q][d];
                     double gd = g * delta;
                     csd[d] += gd;
-                    gc_l[d] += gd * delta;
+                    if constexpr (GC) gc_l[d] += gd * delta;
                 }
             } else {
                 if (ok) {
@@ -1970,7 +1977,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
                 for (int q = 0; q < 4; ++q) {
                     double a = 0.0;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
+                    for (int d = 0; d < ND; ++d) {
                         double diff = (xi[q][d] - xj[d]) * kp.inv_ls[d];
                         a += diff * diff;
                     }
@@ -1987,14 +1994,14 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
                 double Mij = ok ? acc[jj][q] : 0.0;
                 if constexpr (DIST == 0 && KERN == 0) {
                     double g = Mij * Kv[q];
-                    gc_sv += 2.0 * g;
+                    if constexpr (GC) gc_sv += 2.0 * g;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
+                    for (int d = 0; d < ND; ++d) {
                         double delta = xj[d] - xi[q][d];
                         double gd = g * delta;
                         colsum[d] += gd;
                         rowsum[q][d] -= gd;
-                        gc_l[d] += 2.0 * gd * delta;
+                        if constexpr (GC) gc_l[d] += 2.0 * gd * delta;
                     }
                 } else {
                     if (ok) {
@@ -2015,10 +2022,13 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         // column sums of tile column jj over this wave's 16 rows (zero for a wave without that tile)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            double v = colsum[d];
-            if constexpr (DIST == 0 && KERN == 0) v *= fx[d];
-            v += shfl_xor_d(v, 16);
-            v += shfl_xor_d(v, 32);
+            double v = 0.0;
+            if (d < ND) {
+                v = colsum[d];
+                if constexpr (DIST == 0 && KERN == 0) v *= fx[d];
+                v += shfl_xor_d(v, 16);
+                v += shfl_xor_d(v, 32);
+            }
             csum[jj][d] = v;
         }
     }
@@ -2035,8 +2045,11 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
             double rs[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                rs[d] = row16_sum(rowsum[q][d]);
-                if constexpr (DIST == 0 && KERN == 0) rs[d] *= fx[d];
+                rs[d] = 0.0;
+                if (d < ND) {
+                    rs[d] = row16_sum(rowsum[q][d]);
+                    if constexpr (DIST == 0 && KERN == 0) rs[d] *= fx[d];
+                }
             }
             if (lr < 3) {
                 double v = (lr == 0) ? rs[0] : ((lr == 1) ? rs[1] : rs[2]);
@@ -2049,10 +2062,12 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? 3 : 2) void k_mgrad
         for (int d = 0; d < 3; ++d) gc_l[d] *= fl[d];
     }
     double gcv[5] = {gc_tr, gc_sv, gc_l[0], gc_l[1], gc_l[2]};
-    if (want_gc) {
+    if constexpr (GC) {
+        if (want_gc) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
-            for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+            for (int t = 0; t < 5; ++t)
+                for (int off = 32; off >= 1; off >>= 1) gcv[t] += shfl_xor_d(gcv[t], off);
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -2425,10 +2440,16 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     int TBm = (ut.max_T + 3) / 4;
     dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
     if (dist_id == 0 && kern_id == 0) {
-        if (have_K) hipLaunchKernelGGL((k_mgrad<0, 0, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-        else hipLaunchKernelGGL((k_mgrad<0, 0, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        bool fast = !want_gc && kp.dx <= 2;
+        if (have_K) {
+            if (fast) hipLaunchKernelGGL((k_mgrad<0, 0, true, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, true, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_mgrad<0, 0, false, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, false, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        }
     } else {
-        hipLaunchKernelGGL((k_mgrad<1, 1, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        hipLaunchKernelGGL((k_mgrad<1, 1, false, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
     }
 }
 
