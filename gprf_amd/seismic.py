@@ -67,6 +67,11 @@ class PDTree(object):
             pvec = evec[:, np.argmax(ev)]
             a = _project(data, pvec)
             med = np.median(a)
+            if not np.any(a < med):
+                # every point on one side (coincident events, or more than half of them on the median): the reference
+                # recursion would never end here; the points stay together as one oversized leaf
+                leaf_pts[k] = idx
+                continue
             vec[k], center[k], split[k] = pvec, mean, med
             stack.append((idx[a >= med], k, True))      # popped second
             stack.append((idx[a < med], k, False))      # popped first: left subtree numbered before the right one

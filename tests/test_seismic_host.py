@@ -134,3 +134,12 @@ def test_failed_evaluation_is_answered_like_the_reference():
     assert f == 1e10 and gr.shape == o.full0.shape and np.all(np.isfinite(gr))     # run_seismic.py:155-159
     f2, _ = o(o.full0)
     assert f2 < 1e9
+
+
+def test_coincident_events_end_in_one_leaf_instead_of_splitting_forever():
+    X = np.concatenate([np.tile([[10.0, 20.0, 5.0]], (50, 1)), seismic.synthetic_events(100, seed=3)])
+    blocks, reblock = seismic.pdtree_cluster(X, blocksize=30)
+    assert sorted(np.concatenate(blocks).tolist()) == list(range(150))
+    big = [b for b in blocks if len(b) >= 30]
+    assert len(big) == 1 and set(range(50)) <= set(big[0].tolist())     # the 50 duplicates could not be split
+    assert all(np.array_equal(a, b) for a, b in zip(reblock(X), blocks))
