@@ -846,8 +846,17 @@ int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
 
 int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
     if (!c) return GPRF_ERR_ARG;
-    if (!jitter) c->unit_jitter.clear();
-    else c->unit_jitter.assign(jitter, jitter + n_units);
+    if (!jitter) {
+        // the drivers clear the jitter before every evaluation (jitchol is stateless): clearing what is already
+        // clear must not cost a rebuild of the unit tables
+        if (c->unit_jitter.empty()) return GPRF_OK;
+        c->unit_jitter.clear();
+    } else {
+        if (n_units < 0) return GPRF_ERR_ARG;
+        if ((size_t)n_units == c->unit_jitter.size() && std::equal(jitter, jitter + n_units, c->unit_jitter.begin()))
+            return GPRF_OK;
+        c->unit_jitter.assign(jitter, jitter + n_units);
+    }
     c->units_dirty = true;
     return GPRF_OK;
 }
