@@ -1707,7 +1707,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
-template <int DIST, int KERN, bool HAVEK, bool FAST>
+template <int DIST, int KERN, bool HAVEK, int FAST>
 __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
@@ -1881,7 +1881,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
     // task): the third coordinate's terms and the theta sums are compiled out of the reductions, whose VALU volume
     // is what bounds this kernel
     constexpr int ND = FAST ? 2 : 3;
-    constexpr bool GC = !FAST;
+    constexpr bool GC = FAST != 1;
     double rowsum[4][3], xi[4][XN];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -2440,16 +2440,20 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     int TBm = (ut.max_T + 3) / 4;
     dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
     if (dist_id == 0 && kern_id == 0) {
-        bool fast = !want_gc && kp.dx <= 2;
+        // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
+        int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
+        if (const char *e = getenv("GPRF_MGRAD_FAST")) { if (e[0] == '0') fast = 0; }      // diagnostics: general form
         if (have_K) {
-            if (fast) hipLaunchKernelGGL((k_mgrad<0, 0, true, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, true, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, true, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
         } else {
-            if (fast) hipLaunchKernelGGL((k_mgrad<0, 0, false, true>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, false, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, false, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
         }
     } else {
-        hipLaunchKernelGGL((k_mgrad<1, 1, false, false>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
     }
 }
 

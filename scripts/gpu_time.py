@@ -16,10 +16,11 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20, tag=""):
         # ablation runs produce garbage (possibly NOT_PD): time the raw C-ABI call and ignore the status
         g._push_neighbors(nbrs)
         ctx = g._ctx
-        ctx.eval(X, True, False)
+        gc = bool(os.environ.get("GC"))      # GC=1: hyper-parameter gradient too (task xcov)
+        ctx.eval(X, True, gc)
         ctx.set_timing(True, reset=True)
         for _ in range(reps):
-            ctx.eval(X, True, False)
+            ctx.eval(X, True, gc)
         st = ctx.get_timing()
         print("%s pairs=%d RAW: stages(us) %s" % (tag, len(nbrs), {k: round(v * 1e3, 1) for k, v in st.items() if k != "count"}))
         g.close(); return
