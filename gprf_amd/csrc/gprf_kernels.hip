@@ -1708,7 +1708,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
 template <int DIST, int KERN, bool HAVEK, int FAST>
-__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
     // reductions at the end find them in LDS instead of starting with exposed global loads
