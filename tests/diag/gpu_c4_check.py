@@ -19,7 +19,11 @@ for _ in range(10):
     t = time.time(); g.llgrad(grad_X=True, grad_cov=True); ts.append(time.time() - t)
 st = g._ctx.get_timing()
 print("median %.2f ms  stages(us) %s  work %s" % (np.median(ts) * 1e3, {k: round(v * 1e3) for k, v in st.items() if k != 'count'}, g._ctx.work_estimate()))
-t = time.time(); g.update_X(X + 1e-4 * rng.randn(n, 2)); g.llgrad(grad_X=True); print("update_X + llgrad %.1f ms" % ((time.time() - t) * 1e3))
+t = time.time(); g.update_X(X + 1e-4 * rng.randn(n, 2)); g.llgrad(grad_X=True); print("first update_X + llgrad (centres uploaded, everything re-blocked) %.1f ms" % ((time.time() - t) * 1e3))
+for step in (1e-4, 1e-4, 1e-7, 1e-7):      # a few points change block / nobody does
+    X2 = g.X + step * rng.randn(n, 2)
+    t = time.time(); g.update_X(X2); t1 = time.time(); g.llgrad(grad_X=True, grad_cov=True); t2 = time.time()
+    print("step %.0e: update_X %.2f ms  llgrad %.2f ms" % (step, (t1 - t) * 1e3, (t2 - t1) * 1e3))
 # spot check against the oracle on the Bethe-weighted sum restricted to two units
 from oracle.gprf_ref import GPRFRef
 from oracle.vector_tree import GPCov as OC
