@@ -295,7 +295,7 @@ class Context(object):
         m, mp, _ = self.debug_unit_shape(l)
         tbm = max((self.max_T() + 3) // 4, 1) if what in (7, 8) else 0
         shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,), 6: (8,),
-                 7: (mp, tbm, XPAD), 8: (mp, tbm, XPAD)}[what]
+                 7: (mp, tbm, XPAD), 8: (mp, tbm, XPAD), 9: (self.ncov,)}[what]
         out = np.zeros(shape)
         self._check(self.lib.gprf_debug_fetch(self.h, l, what, dptr(out), out.size), "gprf_debug_fetch")
         return out

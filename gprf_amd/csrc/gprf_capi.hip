@@ -1008,6 +1008,23 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
             out[0] = -0.5 * out[2] - 0.5 * c->dy * out[1] - 0.5 * c->dy * c->l_m[l] * std::log(2.0 * M_PI);
             return GPRF_OK;
         }
+        case 9: {   // the unit's own (unweighted) hyper-parameter gradient, theta order (gprf.py:577-584)
+            if (out_len < c->ncov) return GPRF_ERR_ARG;
+            int64_t tbm = std::max((c->max_T + 3) / 4, 1);
+            int64_t tb = (mp / 16 + 3) / 4;
+            int64_t npair = tb * (tb + 1) / 2, stride = tbm * (tbm + 1) / 2;
+            std::vector<double> part((size_t)std::max<int64_t>(npair, 1) * GC_SLOTS, 0.0);
+            if (npair > 0)
+                HIP_TRY(c, hipMemcpy(part.data(), c->d_gcpart.p + (size_t)l * stride * GC_SLOTS,
+                                     (size_t)npair * GC_SLOTS * sizeof(double), hipMemcpyDeviceToHost));
+            double g[5] = {0, 0, 0, 0, 0};
+            for (int64_t P = 0; P < npair; ++P)
+                for (int t = 0; t < 5; ++t) g[t] += part[(size_t)P * GC_SLOTS + t];
+            out[0] = 0.5 * g[0];
+            out[1] = 0.5 * g[1] / c->theta[1];
+            for (int t = 2; t < c->ncov; ++t) out[t] = 0.5 * g[t];
+            return GPRF_OK;
+        }
         default: return GPRF_ERR_ARG;
     }
     if (out_len < len) return GPRF_ERR_ARG;

@@ -27,9 +27,19 @@ def _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu):
             K[s:s + step] = cov.wfn_params[0] * torch.exp(-1.0 * d * d)
             del diff, d
         K.diagonal().add_(noise_var)
-        L = torch.linalg.cholesky(K)
-        del K
-        Y = (L @ torch.as_tensor(Z, dtype=torch.float64, device=dev)).cpu().numpy()
+        if n > 32768:
+            # BASELINE config 4 (N = 80500: 52 GB of fp64): factor in place, panel by panel, out of GEMMs whose
+            # operands stay below 2^31 elements (a second N x N buffer and the library routine's index range are
+            # both avoided); only the lower triangle is ever read
+            L = _cholesky_lower_inplace(K)
+        else:
+            L = torch.linalg.cholesky(K)
+            del K
+        Zd = torch.as_tensor(Z, dtype=torch.float64, device=dev)
+        Y = torch.empty((n, Zd.shape[1]), dtype=torch.float64, device=dev)
+        for s in range(0, n, 8192):                       # row panels of the lower triangle: no N x N temporary
+            Y[s:s + 8192] = torch.tril(L[s:s + 8192, :s + 8192], diagonal=s) @ Zd[:s + 8192]
+        Y = Y.cpu().numpy()
         del L
         torch.cuda.empty_cache()
         return Y
@@ -43,6 +53,28 @@ def _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu):
     if info != 0:
         raise np.linalg.LinAlgError("prior covariance not positive definite")
     return np.dot(L, Z)
+
+
+def _cholesky_lower_inplace(A, nb=2048, wide=16384):
+    """Right-looking blocked Cholesky of the symmetric positive definite torch matrix ``A`` (fp64, on the GPU),
+    overwriting its lower triangle with L (A = L L^T); the strict upper triangle is left as it was."""
+    import torch
+    n = A.shape[0]
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        Lkk = torch.linalg.cholesky(A[k:e, k:e])
+        A[k:e, k:e] = Lkk
+        if e == n:
+            break
+        # panel: P = A[e:, k:e] Lkk^-T
+        P = torch.linalg.solve_triangular(Lkk, A[e:, k:e].mT, upper=False).mT.contiguous()
+        A[e:, k:e] = P
+        # trailing update of the lower triangle, one wide block column at a time (diagonal block downwards)
+        for j in range(e, n, wide):
+            je = min(j + wide, n)
+            A[j:, j:je].addmm_(P[j - e:], P[j - e:je - e].mT, alpha=-1.0)
+        del P
+    return A
 
 
 def sample_synthetic(seed=1, n=400, xd=2, yd=10, lscale=0.1, noise_var=0.01, use_gpu=False):

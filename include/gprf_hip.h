@@ -158,7 +158,8 @@ int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
  * 1 W = U^-T (mp x mp, lower), 2 Z = U^-T Y (mp x 64), 3 At = (K^-1 Y)^T (64 x mp),
  * 4 per-row gradient slab (mp x 4), 5 [ll_u, logdet_u, zz_u, info_u], 6 eight in-kernel cycle
  * counters of diagnostic builds, 7 / 8 the gradient reduction's per-block column / row partials
- * (mp x TBm x 4, TBm = ceil(max local unit rows / 64)).  mp = m rounded up to 16.
+ * (mp x TBm x 4, TBm = ceil(max local unit rows / 64)), 9 the unit's own (unweighted) gradient with respect to
+ * theta (ntheta doubles; needs an evaluation run with want_gradC).  mp = m rounded up to 16.
  * `stop_after` for gprf_debug_run: run the pipeline only up to a stage (0 = fill only ... 6 = all). */
 int gprf_debug_run(gprf_ctx *ctx, const double *X, int32_t stop_after);
 int gprf_debug_fetch(gprf_ctx *ctx, int32_t local_unit, int32_t what, double *out, int64_t out_len);

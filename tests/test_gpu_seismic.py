@@ -110,3 +110,48 @@ def test_device_tree_routing_equals_host_routing():
     changed, _ = g._ctx.assign_blocks(np.ascontiguousarray(far))
     assert not changed
     g.close(); slow.close()
+
+
+def test_config5_block_size_lld_matern32_units_above_256_points():
+    """BASELINE configs[4]'s own shape (run_seismic.py:299-301, 375): ("lld","matern32") with 40 km lengthscales,
+    principal-direction-tree blocks of fewer than 210 events, edges above 0.6 — block pairs of 257..418 points, which
+    take the K-pool fill (k_fill<lld, matern32>), the generic Cholesky (k_potrf) and the 28-tile forward substitution
+    instead of the register-resident kernels the small stand-in above exercises.  Against the oracle's GPRFRef on the
+    same partition: ll relative 1e-11, gradX 1e-9 of its largest entry, hyper-gradient relative 1e-8."""
+    from gprf_amd import GPCov, seismic
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    n, yd = 3000, 6
+    X = seismic.synthetic_events(n, seed=0)
+    Y = np.random.RandomState(1).randn(n, yd)
+    blocks, reblock = seismic.pdtree_cluster(X, 210)
+    ls = [40.0, 40.0]
+    g = GPRF(X, Y, reblock, GPCov([1.0], ls, "lld", "matern32"), 0.1, block_idxs=blocks, neighbor_threshold=0.6)
+    sz = [len(b) for b in blocks]
+    assert max(sz) < 210 and len(g.neighbors) > 0
+    pair_sizes = [sz[i] + sz[j] for (i, j) in g.neighbors]
+    assert max(pair_sizes) > 256 and max(pair_sizes) <= 418
+    r = GPRFRef(X, Y, None, OC([1.0], ls, "lld", "matern32"), 0.1, block_idxs=g.block_idxs, neighbors=g.neighbors)
+    for task_cov in (False, True):
+        a = g.llgrad(grad_X=True, grad_cov=task_cov)
+        b = r.llgrad(grad_X=True, grad_cov=task_cov)
+        assert np.isclose(a[0], b[0], rtol=1e-11)
+        assert np.max(np.abs(a[1] - b[1])) <= 1e-9 * np.max(np.abs(b[1]))
+        if task_cov:
+            assert np.allclose(a[2], b[2], rtol=1e-8)
+    # the events move (some change leaf), the hypers move: still the same numbers as the oracle
+    rng = np.random.RandomState(2)
+    X2 = X + rng.randn(n, 3) * [0.05, 0.05, 2.0]
+    X2[:, 2] = np.abs(X2[:, 2])
+    g.update_X(X2)
+    g.update_covs(np.array([[0.12, 0.9, 35.0, 45.0]]))
+    r.block_fn = seismic.pdtree_cluster(X, 210)[1]
+    r.update_X(X2)
+    r.update_covs(np.array([[0.12, 0.9, 35.0, 45.0]]))
+    assert all(np.array_equal(p, q) for p, q in zip(g.block_idxs, r.block_idxs))
+    a, b = g.llgrad(grad_X=True, grad_cov=True), r.llgrad(grad_X=True, grad_cov=True)
+    assert np.isclose(a[0], b[0], rtol=1e-11)
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-9 * np.max(np.abs(b[1]))
+    assert np.allclose(a[2], b[2], rtol=1e-8)
+    g.close()
