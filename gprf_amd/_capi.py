@@ -8,7 +8,7 @@ import numpy as np
 
 from . import build as _build
 
-GPRF_OK, GPRF_NOT_PD = 0, 1
+GPRF_OK, GPRF_NOT_PD, GPRF_RETRY = 0, 1, 2
 N_STAGES = 7
 STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")   # grad = k_mgrad + k_gx_finalize
 DIST_IDS = {"euclidean": 0, "lld": 1}
@@ -35,15 +35,19 @@ SIGNATURES = {
     "gprf_set_block_assignment": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_set_centers": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_assign_blocks": (ctypes.c_int, [_vp, _dp, _i32p, _i32p]),
+    "gprf_get_block_assignment": (ctypes.c_int, [_vp, _i32p]),
     "gprf_set_split_tree": (ctypes.c_int, [_vp, _i32, _i32, _i32, _dp, _dp, _dp, _i32p, _i32p, _i32p]),
     "gprf_set_shard": (ctypes.c_int, [_vp, _i32, _i32]),
     "gprf_partition_units": (ctypes.c_int, [_i32, _i32p, _i32, _i32, _i32p]),
     "gprf_set_unit_jitter": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_eval": (ctypes.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, _dp, _i32p]),
+    "gprf_update_eval": (ctypes.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, _dp, _i32p, _i32p]),
     "gprf_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "gprf_update_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "gprf_eval_status": (ctypes.c_int, [_vp, _i32p]),
     "gprf_num_units": (ctypes.c_int, [_vp, _i32p, _i32p]),
     "gprf_work_estimate": (ctypes.c_int, [_vp, _dp, _dp]),
+    "gprf_table_builds": (ctypes.c_int, [_vp, _i32p]),
     "gprf_set_timing": (ctypes.c_int, [_vp, _i32]),
     "gprf_get_timing": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_debug_run": (ctypes.c_int, [_vp, _dp, _i32]),
@@ -77,7 +81,7 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if build_if_missing and (not os.path.exists(path)):
+    if build_if_missing and _build._stale() and _build.have_compiler():
         _build.build()
     if not os.path.exists(path):
         raise GprfHipError("libgprf_hip.so is missing (%s); run `python -m gprf_amd.build`" % path)
@@ -243,10 +247,35 @@ class Context(object):
         self._check(rc, "gprf_eval")
         return rc, ll.value, gx, gc, bad.value
 
-    def eval_device(self, d_X_ptr, want_gx, want_gc, d_out_ptr, stream_ptr=None):
-        rc = self.lib.gprf_eval_device(self.h, _vp(d_X_ptr), 1 if want_gx else 0, 1 if want_gc else 0,
-                                       _vp(d_out_ptr), _vp(stream_ptr) if stream_ptr else None)
-        self._check(rc, "gprf_eval_device")
+    def update_eval(self, X, want_gx, want_gc):
+        """update_X + llgrad in one call (device re-blocking): -> (rc, ll, gradX, gradC, first_bad_unit, reblocked)"""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.shape == (self.n, self.dx)
+        ll = ctypes.c_double(0.0)
+        gx = np.empty((self.n, self.dx)) if want_gx else None
+        gc = np.empty((self.ncov,)) if want_gc else None
+        bad, reb = _i32(-1), _i32(0)
+        rc = self.lib.gprf_update_eval(self.h, dptr(X), 1 if want_gx else 0, 1 if want_gc else 0, ctypes.byref(ll),
+                                       dptr(gx) if want_gx else None, dptr(gc) if want_gc else None, ctypes.byref(bad),
+                                       ctypes.byref(reb))
+        self._check(rc, "gprf_update_eval")
+        return rc, ll.value, gx, gc, bad.value, bool(reb.value)
+
+    def get_block_assignment(self):
+        out = np.empty(self.n, dtype=np.int32)
+        self._check(self.lib.gprf_get_block_assignment(self.h, out.ctypes.data_as(_i32p)), "gprf_get_block_assignment")
+        return out
+
+    def table_builds(self):
+        b = _i32(0)
+        self._check(self.lib.gprf_table_builds(self.h, ctypes.byref(b)), "gprf_table_builds")
+        return b.value
+
+    def eval_device(self, d_X_ptr, want_gx, want_gc, d_out_ptr, stream_ptr=None, reblock=False):
+        fn = self.lib.gprf_update_eval_device if reblock else self.lib.gprf_eval_device
+        rc = fn(self.h, _vp(d_X_ptr), 1 if want_gx else 0, 1 if want_gc else 0,
+                _vp(d_out_ptr), _vp(stream_ptr) if stream_ptr else None)
+        self._check(rc, "gprf_update_eval_device" if reblock else "gprf_eval_device")
         return rc
 
     def eval_status(self):
@@ -295,7 +324,7 @@ class Context(object):
         m, mp, _ = self.debug_unit_shape(l)
         tbm = max((self.max_T() + 3) // 4, 1) if what in (7, 8) else 0
         shape = {0: (mp, mp), 1: (mp, mp), 2: (mp, YPAD), 3: (YPAD, mp), 4: (mp, XPAD), 5: (4,), 6: (8,),
-                 7: (mp, tbm, XPAD), 8: (mp, tbm, XPAD), 9: (self.ncov,)}[what]
+                 7: (mp, tbm, XPAD), 8: (mp, tbm, XPAD), 9: (self.ncov,), 10: (mp,)}[what]
         out = np.zeros(shape)
         self._check(self.lib.gprf_debug_fetch(self.h, l, what, dptr(out), out.size), "gprf_debug_fetch")
         return out

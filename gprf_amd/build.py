@@ -18,6 +18,10 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def have_compiler():
+    return os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB

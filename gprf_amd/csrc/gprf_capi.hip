@@ -1,5 +1,14 @@
 // gprf_capi.hip — host side of libgprf_hip.so: context, unit tables, workspace pools, the C ABI of
 // include/gprf_hip.h.  No torch, no Python; plain pointers and sizes.
+//
+// Who builds what.  The STATIC tables depend on the neighbour list, the shard and the jitter only: unit -> (block i,
+// block j), Bethe weight, block -> units CSR, launch order; they are built here on the host (rebuild_static) and
+// uploaded in one staged copy.  Everything that depends on the PARTITION — unit sizes, row / matrix offsets, the unit
+// row -> point table, a point's position inside its block — is built on the device (k_unit_scan, k_place) from the
+// block of every point, which is either computed on the device too (k_assign / k_route: the re-blocking the
+// reference's drivers do before every evaluation, gprf.py:169-174) or uploaded (gprf_set_blocks).  An evaluation that
+// re-partitions therefore never returns to the host in the middle: one upload of X, one download of the result
+// (+ a few control words: sizes, status), one synchronisation.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -71,58 +80,47 @@ struct gprf_ctx {
     // host-side model state (what the reference keeps on the GPRF object)
     std::vector<double> theta;
     bool have_Y = false, have_theta = false, have_blocks = false;
-    int n_blocks = 0, n_pairs = 0;
-    std::vector<int64_t> block_ptr;
-    std::vector<int32_t> block_pts;
+    int n_blocks = 0, n_pairs = 0, n_chunks = 0;
     std::vector<int32_t> pairs;           // (i, j) rows
     std::vector<double> unit_jitter;      // global unit ids
-    bool units_dirty = true;
+    // the partition as the host knows it: block sizes (exact after every synchronised evaluation); the block of every
+    // point / its position inside the block only while they were given by the host (gprf_set_blocks)
+    std::vector<int32_t> h_bsize, h_assign_host, h_posb_host;
+    bool host_blocks_dirty = false;       // h_assign_host / h_posb_host / h_bsize wait to be uploaded
+    bool static_dirty = true;             // neighbour list / shard / block count changed
+    bool jitter_dirty = false;
+    bool need_build = true;               // the device tables must be rebuilt at the next enqueue, changed or not
+    bool assign_valid = false;            // d_assign holds the partition the device tables were built from
 
-    // local units
-    int n_local = 0, max_T = 0;
-    long total_rows = 0;
-    int64_t total_mat = 0;
-    std::vector<int32_t> l_global, l_m, l_rowoff;
+    // local units (static part; sizes / offsets mirror the device tables only on demand: refresh_host_units)
+    int n_local = 0, max_T = 0;           // max_T: the launch-wide bound
+    int64_t cap_rows = 0, cap_mat = 0;
+    std::vector<int32_t> l_global, l_bi, l_bj, l_m, l_rowoff;
     std::vector<int64_t> l_matoff;
+    int64_t cur_rows = 0, cur_mat = 0;
     double work_flops = 0, work_fill_bytes = 0;
 
     // device state
     DevBuf<double> d_X, d_Y, d_out;
-    // tables: views into the single staged table buffer d_tab (see rebuild_units)
-    template <typename T> struct View { T *p = nullptr; void release() { p = nullptr; } };
-    View<int32_t> d_m, d_rowoff, d_upt, d_slot_row, d_ids;
-    DevBuf<int32_t> d_row_unit;           // filled on the device (k_row_unit)
-    std::vector<int32_t> w_upt, w_slot_row, w_pcnt;   // rebuild_units scratch (kept: no allocation per re-blocking)
-    std::vector<int64_t> w_slot_ptr;
-    View<int64_t> d_matoff, d_slot_ptr;
+    template <typename T> struct View { T *p = nullptr; };
+    View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
-    DevBuf<int32_t> d_info;
-    // device re-blocking (gprf_set_centers / gprf_assign_blocks)
+    DevBuf<int32_t> d_m, d_rowoff, d_offj, d_upt, d_assign, d_posb, d_rank, d_cnt;
+    DevBuf<int64_t> d_matoff;
+    DevBuf<int32_t> d_res;                // [ctl (CTL_WORDS) | info (n_local) | bsize (n_blocks)] : one download per evaluation
+    PinBuf<int32_t> h_res, h_up;          // ... and the staging buffer of an uploaded partition
+    size_t res_words = 0;
+    // device re-blocking (gprf_set_centers / gprf_set_split_tree)
     DevBuf<double> d_cs, d_c2;            // centres as structure of arrays [dx][nc] and their squared norms
-    DevBuf<int32_t> d_assign, d_changed;  // current block of every point; "somebody moved" flag
-    PinBuf<int32_t> h_assign, h_changed;
-    int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
     int n_centers = 0;
-    // ... or through a split tree (gprf_set_split_tree): node arrays, leaf -> block id
     DevBuf<double> d_tvec, d_tcenter, d_tsplit;
     DevBuf<int32_t> d_tleft, d_tright, d_tleaf;
     int tree_nodes = 0, tree_dim = 0, tree_wrap = 0;
-    bool assign_valid = false;            // d_assign holds the partition the unit tables were built from
-    DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Yu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
+    int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
+    DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
-    PinBuf<int32_t> h_info;
-
-    // stream groups: the local units are dealt round-robin (by descending cost) into n_groups sets; each set's
-    // fill->potrf->solve->at->grad chain runs on its own stream so that the latency-bound factorisation
-    // of one set overlaps the throughput-bound stages of another; joined before the assembly
-    static constexpr int MAX_GROUPS = 8;
-    int n_groups = 1;
-    hipStream_t gstream[MAX_GROUPS] = {};
-    hipEvent_t gev_start = nullptr, gev_done[MAX_GROUPS] = {};
-    bool groups_ready = false;
-    int group_begin[MAX_GROUPS + 1] = {};   // ranges into d_ids
 
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
@@ -136,7 +134,10 @@ struct gprf_ctx {
     double stage_ms_sum[GPRF_N_STAGES] = {};
     double stage_ms_last[GPRF_N_STAGES] = {};
     bool eval_pending = false;
-    hipEvent_t ev_tables = nullptr;   // recorded on the context stream after the table upload + Y gather
+    bool pending_reblocked = false;       // the pending evaluation ran the partition kernel
+    hipStream_t last_stream = nullptr;    // stream of the last enqueue (gprf_eval_status synchronises it)
+    hipEvent_t ev_tables = nullptr;       // recorded on the context stream after a table upload
+    hipEvent_t ev_last = nullptr;         // recorded behind the last evaluation on whatever stream it went to
 };
 
 namespace {
@@ -155,6 +156,10 @@ int fail(gprf_ctx *c, int code, const std::string &msg) {
 
 inline int pad16(int m) { return (m + 15) & ~15; }
 
+int32_t *res_ctl(gprf_ctx *c) { return c->d_res.p; }
+int32_t *res_info(gprf_ctx *c) { return c->d_res.p + CTL_WORDS; }
+int32_t *res_bsize(gprf_ctx *c) { return c->d_res.p + CTL_WORDS + std::max(c->n_local, 0); }
+
 UnitTab make_tab(gprf_ctx *c) {
     UnitTab t;
     t.m = c->d_m.p;
@@ -163,7 +168,6 @@ UnitTab make_tab(gprf_ctx *c) {
     t.weight = c->d_weight.p;
     t.jitter = c->d_jitter.p;
     t.upt = c->d_upt.p;
-    t.row_unit = c->d_row_unit.p;
     t.n_units = c->n_local;
     t.max_T = c->max_T;
     t.ids = c->d_ids.p;
@@ -171,11 +175,23 @@ UnitTab make_tab(gprf_ctx *c) {
     return t;
 }
 
+BuildTab make_build(gprf_ctx *c) {
+    BuildTab b;
+    b.assign = c->d_assign.p; b.posb = c->d_posb.p; b.rank = c->d_rank.p; b.cnt = c->d_cnt.p;
+    b.bsize = res_bsize(c);
+    b.unit_bi = c->d_unit_bi.p; b.unit_bj = c->d_unit_bj.p; b.bu_ptr = c->d_bu_ptr.p; b.bu_ent = c->d_bu_ent.p;
+    b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
+    b.ctl = res_ctl(c);
+    b.n = c->n; b.n_blocks = c->n_blocks; b.n_local = c->n_local; b.n_chunks = c->n_chunks;
+    b.cap_rows = c->cap_rows; b.cap_mat = c->cap_mat; b.maxT_bound = c->max_T;
+    return b;
+}
+
 Pools make_pools(gprf_ctx *c) {
     Pools p;
-    p.K = c->d_K.p; p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Yu = c->d_Yu.p; p.Z = c->d_Z.p;
+    p.K = c->d_K.p; p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Y = c->d_Y.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
-    p.gcpart = c->d_gcpart.p; p.info = c->d_info.p; p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
+    p.gcpart = c->d_gcpart.p; p.info = res_info(c); p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
     return p;
 }
 
@@ -191,23 +207,86 @@ KParams make_kparams(gprf_ctx *c) {
     return k;
 }
 
-// (Re)build the local unit tables after blocks / neighbours / shard / jitter changed.
+// sizes / offsets of the local units as the device derives them (k_unit_scan), recomputed from the block sizes
+void refresh_host_units(gprf_ctx *c) {
+    const int nl = c->n_local;
+    c->l_m.resize(nl); c->l_rowoff.resize(nl); c->l_matoff.resize(nl);
+    int64_t rows = 0, mat = 0;
+    double flops = 0, fbytes = 0;
+    for (int l = 0; l < nl; ++l) {
+        int m = c->h_bsize[c->l_bi[l]] + (c->l_bj[l] >= 0 ? c->h_bsize[c->l_bj[l]] : 0);
+        int mp = pad16(m);
+        c->l_m[l] = m; c->l_rowoff[l] = (int32_t)rows; c->l_matoff[l] = mat;
+        rows += mp; mat += (int64_t)mp * mp;
+        flops += (double)m * m * m + 4.0 * m * m * c->dy;
+        fbytes += 8.0 * m * m;
+    }
+    c->cur_rows = rows; c->cur_mat = mat;
+    c->work_flops = flops; c->work_fill_bytes = fbytes;
+}
+
+// workspace for `rows` padded rows, `mat` matrix elements and units of up to maxT tiles per edge
+int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
+    size_t nl1 = (size_t)std::max(c->n_local, 1);
+    size_t tbm = (size_t)std::max((maxT + 3) / 4, 1);      // 64-point blocks per edge of the largest local unit
+    HIP_TRY(c, c->d_logdet.reserve(nl1));
+    HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
+    HIP_TRY(c, c->d_dbg.reserve(nl1 * 8));
+    HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
+    HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1, 1.0));
+    HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1, 1.0));
+    HIP_TRY(c, c->d_K.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
+    HIP_TRY(c, c->d_U.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
+    HIP_TRY(c, c->d_W.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
+    HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1, 1.0));
+    HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1, 1.0));      // XPAD, or 8 for the lld record
+    HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1, 1.0));
+    HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1, 1.0));
+    HIP_TRY(c, c->d_gXu.reserve((size_t)rows * XPAD + 1, 1.0));
+    HIP_TRY(c, c->d_upt.reserve((size_t)rows + 1, 1.0));
+    return GPRF_OK;
+}
+
+// Workspace capacities for the partitions to come.  Padded rows have a partition-independent bound (a point
+// appears once in every unit that contains its block); the matrix pools get headroom over the present partition and
+// the launch-wide tile bound is the present largest unit: k_unit_scan reports a partition that exceeds any of them,
+// the host grows them and repeats that one evaluation (run_checked).
+int size_workspace(gprf_ctx *c, int64_t min_rows, int64_t min_mat, int min_maxT) {
+    std::vector<int> per_block((size_t)std::max(c->n_blocks, 1), 0);
+    for (int l = 0; l < c->n_local; ++l) {
+        per_block[c->l_bi[l]]++;
+        if (c->l_bj[l] >= 0) per_block[c->l_bj[l]]++;
+    }
+    int mx = 0;
+    for (int v : per_block) mx = std::max(mx, v);
+    int64_t rows_bound = (int64_t)c->n * mx + 15ll * c->n_local;
+    // (capped at twice the present need so that a degenerate neighbour list does not reserve n * n_blocks rows)
+    int64_t rows = std::max<int64_t>(std::max(min_rows, c->cur_rows),
+                                     std::min<int64_t>(rows_bound, 2 * std::max<int64_t>(c->cur_rows, 1) + 4096));
+    int64_t mat = std::max<int64_t>(min_mat, c->cur_mat + c->cur_mat / 4 + 65536);
+    int maxT = min_maxT;
+    for (int l = 0; l < c->n_local; ++l) maxT = std::max(maxT, pad16(c->l_m[l]) / 16);
+    if (rows > c->cap_rows || mat > c->cap_mat || maxT != c->max_T) {
+        if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));      // an evaluation may still use the old pools
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int rc = reserve_workspace(c, std::max(rows, c->cap_rows), std::max(mat, c->cap_mat), maxT);
+        if (rc != GPRF_OK) return rc;
+        c->cap_rows = std::max(rows, c->cap_rows);
+        c->cap_mat = std::max(mat, c->cap_mat);
+        c->max_T = maxT;
+    }
+    return GPRF_OK;
+}
+
+// (Re)build the static tables after neighbours / shard / block count (or a host partition's sizes) changed.
 // Units: blocks 0..n_blocks-1 (gprf.py:236), then pairs in the caller's order (gprf.py:239).
-int rebuild_units(gprf_ctx *c) {
-    static const bool rb_timing = [] { const char *e = getenv("GPRF_REBUILD_TIMING"); return e && e[0] == '1'; }();
-    auto rb_now = [] { return std::chrono::steady_clock::now(); };
-    auto rb_t0 = rb_now();
-    auto rb_lap = [&](const char *what) {
-        if (!rb_timing) return;
-        auto t = rb_now();
-        fprintf(stderr, "[rebuild] %-18s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - rb_t0).count());
-        rb_t0 = t;
-    };
+int rebuild_static(gprf_ctx *c) {
     const int nb = c->n_blocks, np = c->n_pairs;
     const int nu = nb + np;
+    if ((int)c->h_bsize.size() != nb) return fail(c, GPRF_ERR_STATE, "block sizes unknown");
     std::vector<int32_t> um(nu);
     std::vector<int> deg(nb, 0);
-    for (int b = 0; b < nb; ++b) um[b] = (int)(c->block_ptr[b + 1] - c->block_ptr[b]);
+    for (int b = 0; b < nb; ++b) um[b] = c->h_bsize[b];
     for (int q = 0; q < np; ++q) {
         int i = c->pairs[2 * q], j = c->pairs[2 * q + 1];
         if (i < 0 || i >= nb || j < 0 || j >= nb || i == j)
@@ -218,159 +297,93 @@ int rebuild_units(gprf_ctx *c) {
     }
     for (int u = 0; u < nu; ++u)
         if (um[u] > GPRF_MAX_UNIT) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "unit %d has %d points; the kernels accept at most %d per unit", u, um[u],
-                     GPRF_MAX_UNIT);
+            char buf[200];
+            snprintf(buf, sizeof buf, "unit %d has %d points; the kernels accept at most %d per unit (GPRF_MAX_UNIT)", u,
+                     um[u], GPRF_MAX_UNIT);
             return fail(c, GPRF_ERR_ARG, buf);
         }
-    // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy
+    // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy, on the sizes of THIS partition;
+    // the ownership then stays until the next static rebuild (later re-blockings on the device keep it)
     std::vector<int> owner(nu, 0);
     if (c->world > 1 && nu > 0) gprf_partition_units(nu, um.data(), c->dy, c->world, owner.data());
-    c->l_global.clear(); c->l_m.clear(); c->l_rowoff.clear(); c->l_matoff.clear();
+    c->l_global.clear(); c->l_bi.clear(); c->l_bj.clear();
     std::vector<double> weight, jitter;
-    long rows = 0;
-    int64_t mat = 0;
-    int maxT = 0;
-    double flops = 0, fbytes = 0;
     for (int u = 0; u < nu; ++u) {
         if (owner[u] != c->rank) continue;
-        int m = um[u], mp = pad16(m);
         c->l_global.push_back(u);
-        c->l_m.push_back(m);
-        c->l_rowoff.push_back((int32_t)rows);
-        c->l_matoff.push_back(mat);
+        c->l_bi.push_back(u < nb ? u : c->pairs[2 * (u - nb)]);
+        c->l_bj.push_back(u < nb ? -1 : c->pairs[2 * (u - nb) + 1]);
         weight.push_back(u < nb ? (double)(1 - deg[u]) : 1.0);
         jitter.push_back((size_t)u < c->unit_jitter.size() ? c->unit_jitter[u] : 0.0);
-        rows += mp;
-        mat += (int64_t)mp * mp;
-        maxT = std::max(maxT, mp / 16);
-        flops += (double)m * m * m + 4.0 * m * m * c->dy;
-        fbytes += 8.0 * m * m;
     }
     const int nl = (int)c->l_global.size();
     c->n_local = nl;
-    c->max_T = maxT;
-    c->total_rows = rows;
-    c->total_mat = mat;
-    c->work_flops = flops;
-    c->work_fill_bytes = fbytes;
-
-    rb_lap("units + shard");
-    // unit row -> point table and the point -> slots CSR for the deterministic gather (gprf.py:258-273)
-    // Every point sits in exactly one block, so its slots are its block's local units in ascending unit order: counts
-    // and ranks are kept per BLOCK, the row tables are block-wise copies, and the only per-row work left is the scatter
-    // of the slot rows.  (Scratch vectors live in the context: no allocation per re-blocking.)
-    std::vector<int32_t> &upt = c->w_upt;
-    std::vector<int64_t> &slot_ptr = c->w_slot_ptr;
-    std::vector<int32_t> &slot_row = c->w_slot_row;
-    std::vector<int32_t> &pcnt = c->w_pcnt;
-    upt.resize((size_t)rows);
-    std::vector<int32_t> bcnt((size_t)nb, 0), brank((size_t)nb, 0);
+    refresh_host_units(c);
+    // block -> local units, ascending unit id; entry = 2 * unit + side
+    std::vector<int32_t> bu_ptr((size_t)nb + 1, 0), bu_ent;
     for (int l = 0; l < nl; ++l) {
-        int u = c->l_global[l];
-        if (u < nb) bcnt[u]++;
-        else { bcnt[c->pairs[2 * (u - nb)]]++; bcnt[c->pairs[2 * (u - nb) + 1]]++; }
+        bu_ptr[c->l_bi[l] + 1]++;
+        if (c->l_bj[l] >= 0) bu_ptr[c->l_bj[l] + 1]++;
     }
-    pcnt.assign((size_t)c->n, 0);
-    for (int b = 0; b < nb; ++b)
-        for (int64_t k = c->block_ptr[b]; k < c->block_ptr[b + 1]; ++k) pcnt[c->block_pts[k]] += bcnt[b];
-    slot_ptr.resize((size_t)c->n + 1);
-    slot_ptr[0] = 0;
-    for (int p = 0; p < c->n; ++p) slot_ptr[p + 1] = slot_ptr[p] + pcnt[p];
-    slot_row.resize((size_t)slot_ptr[c->n]);
-    for (int l = 0; l < nl; ++l) {
-        int u = c->l_global[l];
-        int32_t *dst = upt.data() + c->l_rowoff[l];
-        auto place = [&](int b, int off) {
-            int64_t s = c->block_ptr[b], e = c->block_ptr[b + 1];
-            const int32_t *pts = c->block_pts.data() + s;
-            int cnt = (int)(e - s);
-            if (cnt) memcpy(dst + off, pts, (size_t)cnt * sizeof(int32_t));
-            int rk = brank[b]++;
-            int32_t base = c->l_rowoff[l] + off;
-            for (int k = 0; k < cnt; ++k) slot_row[slot_ptr[pts[k]] + rk] = base + k;
-            return cnt;
-        };
-        int mfill;
-        if (u < nb) {
-            mfill = place(u, 0);
-        } else {
-            int ni = place(c->pairs[2 * (u - nb)], 0);
-            mfill = ni + place(c->pairs[2 * (u - nb) + 1], ni);
-        }
-        int mp = pad16(c->l_m[l]);
-        for (int r = mfill; r < mp; ++r) dst[r] = -1;
-    }
-    rb_lap("upt + slots");
-    // unit id lists: group g = every n_groups-th unit in descending-cost order (group 0 when n_groups == 1
-    // is simply all units, largest first, so that the long factorizations start first)
-    std::vector<int32_t> ids(nl);
+    for (int b = 0; b < nb; ++b) bu_ptr[b + 1] += bu_ptr[b];
+    bu_ent.resize((size_t)bu_ptr[nb]);
     {
-        std::vector<int> order(nl);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->l_m[a] > c->l_m[b]; });
-        int G = std::max(1, std::min(c->n_groups, gprf_ctx::MAX_GROUPS));
-        // groups are CONTIGUOUS slices of the descending-size order, so that a group of smaller units leaves
-        // its (latency-bound, step-count-proportional) factorisation early and its later stages overlap the
-        // factorisation tail of the big units; group g gets an equal share of the summed cost
-        for (int k = 0; k < nl; ++k) ids[k] = order[k];
-        double total = 0.0, run = 0.0;
-        auto cost = [&](int l) { double mm = c->l_m[l]; return mm * mm * mm + 4.0 * mm * mm * c->dy; };
-        for (int k = 0; k < nl; ++k) total += cost(order[k]);
-        int g = 0;
-        c->group_begin[0] = 0;
-        for (int k = 0; k < nl; ++k) {
-            run += cost(order[k]);
-            if (g + 1 < G && run >= total * (g + 1) / G) c->group_begin[++g] = k + 1;
+        std::vector<int32_t> cur(bu_ptr.begin(), bu_ptr.end() - 1);
+        for (int l = 0; l < nl; ++l) {
+            bu_ent[cur[c->l_bi[l]]++] = 2 * l;
+            if (c->l_bj[l] >= 0) bu_ent[cur[c->l_bj[l]]++] = 2 * l + 1;
         }
-        for (int gg = g + 1; gg <= gprf_ctx::MAX_GROUPS; ++gg) c->group_begin[gg] = nl;
     }
+    // launch order: largest units first, so that the long factorisations start first
+    std::vector<int32_t> ids(nl);
+    std::iota(ids.begin(), ids.end(), 0);
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return c->l_m[a] > c->l_m[b]; });
 
-    rb_lap("order + groups");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    // an evaluation enqueued on a caller's stream may still read the old tables
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(s));
     size_t nl1 = (size_t)std::max(nl, 1);
-    HIP_TRY(c, c->d_logdet.reserve(nl1));
-    HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
-    HIP_TRY(c, c->d_info.reserve(nl1));
-    HIP_TRY(c, c->d_dbg.reserve(nl1 * 8));
-    HIP_TRY(c, c->h_info.reserve(nl1));
-    size_t tbm = (size_t)std::max((maxT + 3) / 4, 1);      // 64-point blocks per edge of the largest local unit
-    HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
-    HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1));
-    HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1));
-    HIP_TRY(c, c->d_K.reserve((size_t)mat + GPRF_POOL_SLACK));
-    HIP_TRY(c, c->d_U.reserve((size_t)mat + GPRF_POOL_SLACK));
-    HIP_TRY(c, c->d_W.reserve((size_t)mat + GPRF_POOL_SLACK));
-    HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1));
-    HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1));      // XPAD, or 8 for the lld record
-    HIP_TRY(c, c->d_Yu.reserve((size_t)rows * YPAD + 1));
-    HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1));
-    HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1));
-    HIP_TRY(c, c->d_gXu.reserve((size_t)rows * XPAD + 1));
-    HIP_TRY(c, c->d_row_unit.reserve((size_t)rows + 1));
-
-    // ONE staged upload: every table is packed (256-byte aligned) into one pinned buffer and copied with a
-    // single asynchronous H2D on the context stream (ten small synchronous copies cost ~0.25 ms per re-blocking)
-    rb_lap("reserve");
-    HIP_TRY(c, hipStreamSynchronize(s));     // the previous staging buffer / tables may still be in use
-    rb_lap("stream sync");
+    c->n_chunks = (c->n + 255) / 256;
+    HIP_TRY(c, c->d_m.reserve(nl1));
+    HIP_TRY(c, c->d_rowoff.reserve(nl1));
+    HIP_TRY(c, c->d_offj.reserve(nl1));
+    HIP_TRY(c, c->d_matoff.reserve(nl1));
+    HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1, 1.0));
+    HIP_TRY(c, c->d_posb.reserve((size_t)c->n + 1, 1.0));
+    HIP_TRY(c, c->d_rank.reserve((size_t)c->n + 1, 1.0));
+    HIP_TRY(c, c->d_cnt.reserve((size_t)std::max(c->n_chunks, 1) * std::max(nb, 1) + 1, 1.0));
+    // the result words [ctl | info | bsize] move when n_local / n_blocks change
+    size_t words = (size_t)CTL_WORDS + nl1 + (size_t)std::max(nb, 1);
+    if (words > c->d_res.cap) {
+        int32_t builds = 0;
+        if (c->d_res.p) HIP_TRY(c, hipMemcpy(&builds, res_ctl(c) + CTL_BUILDS, sizeof(int32_t), hipMemcpyDeviceToHost));
+        c->d_res.release();
+        HIP_TRY(c, c->d_res.reserve(words));
+        HIP_TRY(c, hipMemset(c->d_res.p, 0, c->d_res.cap * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(res_ctl(c) + CTL_BUILDS, &builds, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, c->h_res.reserve(words));
+    c->res_words = (size_t)CTL_WORDS + nl + nb;
+    HIP_TRY(c, hipMemset(c->d_res.p, 0, CTL_BUILDS * sizeof(int32_t)));
+    // block sizes as the host knows them (exact: the device build re-derives them whenever the partition changes)
+    if (nb > 0) HIP_TRY(c, hipMemcpy(res_bsize(c), c->h_bsize.data(), (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice));
     {
+        // ONE staged upload: every table is packed (256-byte aligned) into one pinned buffer and copied with a single
+        // asynchronous H2D on the context stream
         struct Seg { const void *src; size_t bytes; void **dst; };
         Seg segs[] = {
-            {c->l_m.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_m.p},
             {ids.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_ids.p},
-            {c->l_rowoff.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_rowoff.p},
-            {c->l_matoff.data(), (size_t)nl * sizeof(int64_t), (void **)&c->d_matoff.p},
+            {c->l_bi.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_unit_bi.p},
+            {c->l_bj.data(), (size_t)nl * sizeof(int32_t), (void **)&c->d_unit_bj.p},
             {weight.data(), (size_t)nl * sizeof(double), (void **)&c->d_weight.p},
             {jitter.data(), (size_t)nl * sizeof(double), (void **)&c->d_jitter.p},
-            {upt.data(), (size_t)rows * sizeof(int32_t), (void **)&c->d_upt.p},
-            {slot_ptr.data(), slot_ptr.size() * sizeof(int64_t), (void **)&c->d_slot_ptr.p},
-            {slot_row.data(), slot_row.size() * sizeof(int32_t), (void **)&c->d_slot_row.p},
+            {bu_ptr.data(), bu_ptr.size() * sizeof(int32_t), (void **)&c->d_bu_ptr.p},
+            {bu_ent.data(), bu_ent.size() * sizeof(int32_t), (void **)&c->d_bu_ent.p},
         };
-        size_t total = 0;
+        size_t total = 256;
         for (auto &sg : segs) total += (sg.bytes + 255) & ~(size_t)255;
-        total += 256;
         HIP_TRY(c, c->d_tab.reserve(total));
         HIP_TRY(c, c->h_tab.reserve(total));
         size_t off = 0;
@@ -379,20 +392,50 @@ int rebuild_units(gprf_ctx *c) {
             *sg.dst = (void *)(c->d_tab.p + off);
             off += (sg.bytes + 255) & ~(size_t)255;
         }
-        HIP_TRY(c, hipMemcpyAsync(c->d_tab.p, c->h_tab.p, off, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_tab.p, c->h_tab.p, std::max<size_t>(off, 256), hipMemcpyHostToDevice, s));
     }
-    rb_lap("pack + H2D enqueue");
-    // Y rows of every unit (Y never changes; membership does)
-    UnitTab ut = make_tab(c);
-    Pools pl = make_pools(c);
-    launch_row_unit(ut, c->d_row_unit.p, s);
-    launch_gather_y(ut, pl, c->d_Y.p, c->dy, (int)rows, s);
-    HIP_TRY(c, hipGetLastError());
-    // an evaluation enqueued on a caller's stream waits for this event instead of a host sync (enqueue_eval)
+    int rc = size_workspace(c, 0, 0, 0);
+    if (rc != GPRF_OK) return rc;
     if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_tables, s));
-    rb_lap("launches");
-    c->units_dirty = false;
+    c->static_dirty = false;
+    c->jitter_dirty = false;
+    c->need_build = true;
+    return GPRF_OK;
+}
+
+// the jitter vector alone (jitchol's retries): one small upload, no rebuild
+int upload_jitter(gprf_ctx *c) {
+    std::vector<double> jitter((size_t)std::max(c->n_local, 1), 0.0);
+    for (int l = 0; l < c->n_local; ++l) {
+        size_t u = (size_t)c->l_global[l];
+        jitter[l] = u < c->unit_jitter.size() ? c->unit_jitter[u] : 0.0;
+    }
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->n_local > 0)
+        HIP_TRY(c, hipMemcpy(c->d_jitter.p, jitter.data(), (size_t)c->n_local * sizeof(double), hipMemcpyHostToDevice));
+    c->jitter_dirty = false;
+    return GPRF_OK;
+}
+
+// a partition given by the host (gprf_set_blocks): block of every point, position inside the block -> device
+int upload_host_partition(gprf_ctx *c, hipStream_t s) {
+    size_t n = (size_t)c->n;
+    HIP_TRY(c, c->h_up.reserve(2 * n + 1));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));           // the staging buffer of the previous upload
+    if (n) {
+        memcpy(c->h_up.p, c->h_assign_host.data(), n * sizeof(int32_t));
+        memcpy(c->h_up.p + n, c->h_posb_host.data(), n * sizeof(int32_t));
+        HIP_TRY(c, hipMemcpyAsync(c->d_assign.p, c->h_up.p, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_posb.p, c->h_up.p + n, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    if (c->n_blocks > 0)
+        HIP_TRY(c, hipMemcpyAsync(res_bsize(c), c->h_bsize.data(), (size_t)c->n_blocks * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    c->host_blocks_dirty = false;
+    c->assign_valid = true;
+    c->need_build = true;
     return GPRF_OK;
 }
 
@@ -418,18 +461,49 @@ int fold_slot(gprf_ctx *c, int slot) {
     return GPRF_OK;
 }
 
-// enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug)
-int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
-                 int stop_after) {
-    if (c->units_dirty) {
-        int rc = rebuild_units(c);
+// everything host-side an enqueue needs: static tables, jitter, an uploaded partition
+int prepare(gprf_ctx *c, hipStream_t s) {
+    if (c->static_dirty) {
+        int rc = rebuild_static(c);
         if (rc != GPRF_OK) return rc;
     }
+    if (c->jitter_dirty) {
+        int rc = upload_jitter(c);
+        if (rc != GPRF_OK) return rc;
+    }
+    if (c->host_blocks_dirty) {
+        int rc = upload_host_partition(c, c->stream);
+        if (rc != GPRF_OK) return rc;
+        if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_tables, c->stream));
+    }
     if (s != c->stream && c->ev_tables) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_tables, 0));
-    UnitTab ut = make_tab(c);
-    Pools pl = make_pools(c);
-    KParams kp = make_kparams(c);
-    AssembleTab at{c->d_slot_ptr.p, c->d_slot_row.p};
+    return GPRF_OK;
+}
+
+// partition kernel for the points d_X on stream s (centres or tree), leaving ranks / per-chunk counts for the build
+int enqueue_partition(gprf_ctx *c, const double *d_X, hipStream_t s) {
+    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
+    if (c->n_centers != c->n_blocks) return fail(c, GPRF_ERR_STATE, "the centres / tree leaves do not match the block count");
+    BuildTab bt = make_build(c);
+    if (!c->assign_valid) HIP_TRY(c, hipMemsetAsync(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t), s));
+    HIP_TRY(c, hipMemsetAsync(res_ctl(c) + CTL_CHANGED, 0, sizeof(int32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, (size_t)c->n_chunks * c->n_blocks * sizeof(int32_t), s));
+    if (c->tree_nodes > 0)
+        launch_route(d_X, c->dx, c->tree_dim, c->tree_wrap, c->d_tvec.p, c->d_tcenter.p, c->d_tsplit.p, c->d_tleft.p,
+                     c->d_tright.p, c->d_tleaf.p, bt, s);
+    else
+        launch_assign(d_X, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, bt, s);
+    c->assign_valid = true;
+    return GPRF_OK;
+}
+
+// enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug); reblock: first
+// re-partition the points on the device (update_X's block_fn, gprf.py:171-172)
+int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
+                 int stop_after, bool reblock) {
+    int rc = prepare(c, s);
+    if (rc != GPRF_OK) return rc;
     bool tm = c->timing;
     if (tm && !c->ev_valid) {
         for (int r = 0; r < gprf_ctx::RING; ++r)
@@ -439,7 +513,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     int slot = (int)(c->n_timed % gprf_ctx::RING);
     if (tm) {
         if (c->slot_pending[slot]) {
-            int rc = fold_slot(c, slot);
+            rc = fold_slot(c, slot);
             if (rc != GPRF_OK) return rc;
         }
         c->slot_pending[slot] = true;
@@ -447,72 +521,99 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     }
     int stage = 0;
     auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[slot][stage], s); ++stage; };
-    int G = std::max(1, std::min(c->n_groups, gprf_ctx::MAX_GROUPS));
-    bool do_grad = stop_after >= 4 && (want_gx || want_gc);
-    if (G == 1 || tm) {
-        mark();
-        launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, (int)c->total_rows, s);
-        mark();
-        // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
-        bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
-        if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
-        mark();
-        if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s);
-        mark();
-        if (stop_after >= 2) launch_solve(ut, pl, s);
-        mark();
-        if (stop_after >= 3) launch_at(ut, pl, s);
-        mark();
-        if (do_grad) {
-            launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, (int)c->total_rows, !gen, s);
-            launch_gx_finalize(ut, pl, (int)c->total_rows, s);
-        }
-        mark();
-        if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
-        mark();
-    } else {
-        if (!c->groups_ready) {
-            HIP_TRY(c, hipEventCreateWithFlags(&c->gev_start, hipEventDisableTiming));
-            for (int g = 0; g < gprf_ctx::MAX_GROUPS; ++g) {
-                HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
-                HIP_TRY(c, hipEventCreateWithFlags(&c->gev_done[g], hipEventDisableTiming));
-            }
-            c->groups_ready = true;
-        }
-        launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, (int)c->total_rows, s);
-        HIP_TRY(c, hipEventRecord(c->gev_start, s));
-        for (int g = 0; g < G; ++g) {
-            UnitTab ug = ut;
-            ug.ids = c->d_ids.p + c->group_begin[g];
-            ug.n_ids = c->group_begin[g + 1] - c->group_begin[g];
-            hipStream_t gs = c->gstream[g];
-            HIP_TRY(c, hipStreamWaitEvent(gs, c->gev_start, 0));
-            bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ug);
-            if (!gen) launch_fill(c->dist_id, c->kern_id, ug, pl, kp, gs);
-            if (stop_after >= 1) launch_potrf(ug, pl, kp, gen, gs);
-            if (stop_after >= 2) launch_solve(ug, pl, gs);
-            if (stop_after >= 3) launch_at(ug, pl, gs);
-            if (do_grad) launch_grad(c->dist_id, c->kern_id, ug, pl, kp, want_gc, (int)c->total_rows, !gen, gs);
-            HIP_TRY(c, hipEventRecord(c->gev_done[g], gs));
-            HIP_TRY(c, hipStreamWaitEvent(s, c->gev_done[g], 0));
-        }
-        if (do_grad) launch_gx_finalize(ut, pl, (int)c->total_rows, s);
-        if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+    mark();      // stage "gather" = re-partition + table build (when asked for) + the coordinate gather
+    if (reblock) {
+        rc = enqueue_partition(c, d_X, s);
+        if (rc != GPRF_OK) return rc;
+        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, s);
+    } else if (c->need_build) {
+        launch_build_tables(make_build(c), 0, 1, s);
     }
+    c->need_build = false;
+    UnitTab ut = make_tab(c);
+    Pools pl = make_pools(c);
+    KParams kp = make_kparams(c);
+    AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c)};
+    bool do_grad = stop_after >= 4 && (want_gx || want_gc);
+    launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, s);
+    mark();
+    // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
+    bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
+    if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
+    mark();
+    if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s);
+    mark();
+    if (stop_after >= 2) launch_solve(ut, pl, kp, s);
+    mark();
+    if (stop_after >= 3) launch_at(ut, pl, s);
+    mark();
+    if (do_grad) {
+        launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);
+        launch_gx_finalize(ut, pl, s);
+    }
+    mark();
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+    mark();
     HIP_TRY(c, hipGetLastError());
-    // unit status -> pinned host
-    if (c->n_local > 0)
-        HIP_TRY(c, hipMemcpyAsync(c->h_info.p, c->d_info.p, c->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // control words, unit status, block sizes -> pinned host: one download
+    HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!c->ev_last) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_last, s));
     c->eval_pending = true;
+    c->pending_reblocked = reblock;
+    c->last_stream = s;
     return GPRF_OK;
 }
 
-int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit) {
+// the control words of a finished (re-partitioning) evaluation: take over the sizes; an overflow grows the workspace
+// and returns GPRF_RETRY
+int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
+    const int32_t *ctl = c->h_res.p, *bsz = c->h_res.p + CTL_WORDS + c->n_local;
+    bool changed = reblocked_run && ctl[CTL_CHANGED];
+    if (reblocked) *reblocked = changed ? 1 : 0;
+    if (changed || ctl[CTL_OVERFLOW]) {
+        c->h_bsize.assign(bsz, bsz + c->n_blocks);
+        c->h_assign_host.clear();           // the host's copy of an uploaded partition is history now
+        c->h_posb_host.clear();
+        refresh_host_units(c);
+    }
+    if (ctl[CTL_OVERFLOW]) {
+        int64_t mat = ((int64_t)ctl[CTL_MAT_HI] << 32) | (uint32_t)ctl[CTL_MAT_LO];
+        c->need_build = true;
+        if (ctl[CTL_MAXM] > GPRF_MAX_UNIT) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "after re-blocking a unit has %d points; the kernels accept at most %d per unit "
+                     "(GPRF_MAX_UNIT)", ctl[CTL_MAXM], GPRF_MAX_UNIT);
+            return fail(c, GPRF_ERR_ARG, buf);
+        }
+        int rc = size_workspace(c, ctl[CTL_ROWS], mat + mat / 4, ctl[CTL_MAXT]);
+        if (rc != GPRF_OK) return rc;
+        return GPRF_RETRY;
+    }
+    // keep the launch-wide bound at the present largest unit (it only has to grow through the overflow path)
+    if (changed) {
+        int maxT = 0;
+        for (int l = 0; l < c->n_local; ++l) maxT = std::max(maxT, pad16(c->l_m[l]) / 16);
+        if (maxT < c->max_T) {
+            int rc = size_workspace(c, 0, 0, 0);
+            if (rc != GPRF_OK) return rc;
+        }
+    }
+    return GPRF_OK;
+}
+
+// after the stream has been synchronised: GPRF_OK / GPRF_NOT_PD / GPRF_RETRY (the partition outgrew the workspace:
+// it has been grown, enqueue the evaluation again without re-partitioning)
+int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *reblocked) {
     HIP_TRY(c, hipStreamSynchronize(s));
     c->eval_pending = false;
+    if (first_bad_unit) *first_bad_unit = -1;
+    int rc = absorb_control_words(c, c->pending_reblocked, reblocked);
+    if (rc != GPRF_OK) return rc;
+    const int32_t *info = c->h_res.p + CTL_WORDS;
     int bad = -1;
     for (int l = 0; l < c->n_local; ++l)
-        if (c->h_info.p[l] != 0) { bad = c->l_global[l]; break; }
+        if (info[l] != 0) { bad = c->l_global[l]; break; }
     if (first_bad_unit) *first_bad_unit = bad;
     if (bad >= 0) {
         char buf[128];
@@ -520,6 +621,46 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit) {
         c->err = buf;
         return GPRF_NOT_PD;
     }
+    return GPRF_OK;
+}
+
+// host X in -> host result out, optionally re-partitioning first; repeats when the workspace had to grow
+int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll_out, double *gradX_out,
+                double *gradC_out, int32_t *first_bad_unit, bool reblock, int32_t *reblocked) {
+    hipStream_t s = c->stream;
+    size_t nx = (size_t)c->n * c->dx;
+    size_t nout = 1 + nx + c->ncov;
+    memcpy(c->h_X.p, X, nx * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+    int any_reblocked = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int rc = enqueue_eval(c, c->d_X.p, want_gx, want_gc, c->d_out.p, s, 6, reblock);
+        if (rc != GPRF_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->h_out.p, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+        int32_t rb = 0;
+        rc = finish_eval(c, s, first_bad_unit, &rb);
+        any_reblocked |= rb;
+        if (rc == GPRF_RETRY) { reblock = false; continue; }      // the new partition is in d_assign; tables: need_build
+        if (reblocked) *reblocked = any_reblocked;
+        if (rc != GPRF_OK) return rc;
+        *ll_out = c->h_out.p[0];
+        if (want_gx) memcpy(gradX_out, c->h_out.p + 1, nx * sizeof(double));
+        if (want_gc) memcpy(gradC_out, c->h_out.p + 1 + nx, c->ncov * sizeof(double));
+        return GPRF_OK;
+    }
+    return fail(c, GPRF_ERR_STATE, "the unit tables did not fit the workspace after growing it twice");
+}
+
+// the partition as block-of-point, whoever made it
+int fetch_assignment(gprf_ctx *c, int32_t *out) {
+    if (c->host_blocks_dirty && (int)c->h_assign_host.size() == c->n) {
+        memcpy(out, c->h_assign_host.data(), (size_t)c->n * sizeof(int32_t));
+        return GPRF_OK;
+    }
+    if (!c->assign_valid) return fail(c, GPRF_ERR_STATE, "no partition on the device yet");
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->n > 0) HIP_TRY(c, hipMemcpy(out, c->d_assign.p, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return GPRF_OK;
 }
 
@@ -543,7 +684,7 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     c->n = n; c->dx = dx; c->dy = dy; c->dist_id = dist_id; c->kern_id = kern_id; c->device = device;
     c->ndfn = se ? dx : 2;
     c->ncov = 2 + c->ndfn;
-    if (const char *g = getenv("GPRF_GROUPS")) c->n_groups = std::max(1, std::min(atoi(g), (int)gprf_ctx::MAX_GROUPS));
+    c->n_chunks = (n + 255) / 256;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return GPRF_ERR_HIP;
@@ -562,27 +703,24 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
 int gprf_destroy(gprf_ctx *c) {
     if (!c) return GPRF_OK;
     (void)hipSetDevice(c->device);
+    if (c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_m.release(); c->d_rowoff.release();
-    c->d_upt.release(); c->d_slot_row.release(); c->d_info.release(); c->d_matoff.release();
-    c->d_slot_ptr.release(); c->d_weight.release(); c->d_jitter.release();
-    c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release(); c->d_Yu.release();
+    c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
+    c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
+    c->d_posb.release(); c->d_rank.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
+    c->h_res.release(); c->h_up.release();
+    c->d_cs.release(); c->d_c2.release();
+    c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
+    c->d_tleaf.release();
+    c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
-    c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release(); c->d_row_unit.release(); c->h_X.release(); c->h_out.release(); c->h_info.release();
-    c->d_cs.release(); c->d_c2.release(); c->d_assign.release(); c->d_changed.release(); c->h_assign.release(); c->h_changed.release();
+    c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release();
+    c->h_X.release(); c->h_out.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
-    if (c->groups_ready) {
-        (void)hipEventDestroy(c->gev_start);
-        for (int g = 0; g < gprf_ctx::MAX_GROUPS; ++g) {
-            (void)hipStreamSynchronize(c->gstream[g]);
-            (void)hipStreamDestroy(c->gstream[g]);
-            (void)hipEventDestroy(c->gev_done[g]);
-        }
-    }
-    c->d_tab.release(); c->h_tab.release();
     if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;
@@ -593,10 +731,10 @@ const char *gprf_last_error(const gprf_ctx *c) { return c ? c->err.c_str() : "nu
 int gprf_set_Y(gprf_ctx *c, const double *Y) {
     if (!c || !Y) return GPRF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_Y.p, Y, (size_t)c->n * c->dy * sizeof(double), hipMemcpyHostToDevice));
     c->have_Y = true;
-    c->units_dirty = true;  // Yu must be re-gathered
     return GPRF_OK;
 }
 
@@ -617,21 +755,33 @@ int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, con
         if (block_ptr[b + 1] < block_ptr[b]) return fail(c, GPRF_ERR_ARG, "block_ptr must be non-decreasing");
     int64_t tot = block_ptr[n_blocks];
     if (tot > 0 && !point_idx) return GPRF_ERR_ARG;
-    c->assign_valid = false;     // (gprf_assign_blocks sets it again after installing its own partition)
-    for (int64_t k = 0; k < tot; ++k)
-        if (point_idx[k] < 0 || point_idx[k] >= c->n) return fail(c, GPRF_ERR_ARG, "point index out of range");
-    if (n_blocks != c->n_blocks) {
-        // pairs refer to block ids; a different block count invalidates them unless re-set
-        if (c->n_pairs > 0) {
-            for (int q = 0; q < 2 * c->n_pairs; ++q)
-                if (c->pairs[q] >= n_blocks) return fail(c, GPRF_ERR_STATE, "existing neighbor pairs exceed the new block count");
+    if (n_blocks != c->n_blocks && c->n_pairs > 0)
+        for (int q = 0; q < 2 * c->n_pairs; ++q)     // pairs refer to block ids
+            if (c->pairs[q] >= n_blocks) return fail(c, GPRF_ERR_STATE, "existing neighbor pairs exceed the new block count");
+    // a point belongs to at most one block: the scatter of the gradient rows (gprf.py:258-273) is a gather here
+    std::vector<int32_t> assign((size_t)c->n, -1), posb((size_t)c->n, 0), bsize((size_t)n_blocks, 0);
+    for (int b = 0; b < n_blocks; ++b) {
+        bsize[b] = (int32_t)(block_ptr[b + 1] - block_ptr[b]);
+        for (int64_t k = block_ptr[b]; k < block_ptr[b + 1]; ++k) {
+            int32_t p = point_idx[k];
+            if (p < 0 || p >= c->n) return fail(c, GPRF_ERR_ARG, "point index out of range");
+            if (assign[p] >= 0) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "point %d is listed twice (blocks %d and %d): blocks must be disjoint", p, assign[p], b);
+                return fail(c, GPRF_ERR_ARG, buf);
+            }
+            assign[p] = b;
+            posb[p] = (int32_t)(k - block_ptr[b]);
         }
     }
     c->n_blocks = n_blocks;
-    c->block_ptr.assign(block_ptr, block_ptr + n_blocks + 1);
-    c->block_pts.assign(point_idx, point_idx + tot);
+    c->h_assign_host.swap(assign);
+    c->h_posb_host.swap(posb);
+    c->h_bsize.swap(bsize);
+    c->host_blocks_dirty = true;
     c->have_blocks = true;
-    c->units_dirty = true;
+    // launch order, shard and workspace follow the sizes: redone with every host partition
+    c->static_dirty = true;
     return GPRF_OK;
 }
 
@@ -723,17 +873,12 @@ int gprf_set_centers(gprf_ctx *c, int32_t nc, const double *centers) {
     }
     HIP_TRY(c, c->d_cs.reserve(cs.size() + 1));
     HIP_TRY(c, c->d_c2.reserve(c2.size() + 1));
-    HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1));
-    HIP_TRY(c, c->d_changed.reserve(1));
-    HIP_TRY(c, c->h_assign.reserve((size_t)c->n + 1));
-    HIP_TRY(c, c->h_changed.reserve(1));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_cs.p, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_c2.p, c2.data(), c2.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t)));   // -1: everybody "moves" first time
     c->n_centers = nc;
     c->tree_nodes = 0;
-    c->assign_valid = false;
     return GPRF_OK;
 }
 
@@ -764,10 +909,7 @@ int gprf_set_split_tree(gprf_ctx *c, int32_t n_nodes, int32_t dim, int32_t lon_w
     HIP_TRY(c, c->d_tleft.reserve((size_t)n_nodes + 1));
     HIP_TRY(c, c->d_tright.reserve((size_t)n_nodes + 1));
     HIP_TRY(c, c->d_tleaf.reserve((size_t)n_nodes + 1));
-    HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1));
-    HIP_TRY(c, c->d_changed.reserve(1));
-    HIP_TRY(c, c->h_assign.reserve((size_t)c->n + 1));
-    HIP_TRY(c, c->h_changed.reserve(1));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_tvec.p, vec, nd * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tcenter.p, center, nd * sizeof(double), hipMemcpyHostToDevice));
@@ -775,10 +917,8 @@ int gprf_set_split_tree(gprf_ctx *c, int32_t n_nodes, int32_t dim, int32_t lon_w
     HIP_TRY(c, hipMemcpy(c->d_tleft.p, left, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tright.p, right, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tleaf.p, leaf_block, (size_t)n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t)));
     c->tree_nodes = n_nodes; c->tree_dim = dim; c->tree_wrap = lon_wrap ? 1 : 0;
     c->n_centers = n_leaves;
-    c->assign_valid = false;
     return GPRF_OK;
 }
 
@@ -786,36 +926,55 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
     if (!c || !X || !changed) return GPRF_ERR_ARG;
     if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->have_blocks || c->n_blocks != c->n_centers || (int)c->h_bsize.size() != c->n_centers) {
+        // no partition yet: size everything for an even one, the overflow path corrects it
+        c->n_blocks = c->n_centers;
+        c->h_bsize.assign((size_t)c->n_centers, (c->n + c->n_centers - 1) / std::max(c->n_centers, 1));
+        c->h_assign_host.clear();
+        c->h_posb_host.clear();
+        c->host_blocks_dirty = false;
+        c->have_blocks = true;
+        c->static_dirty = true;
+        c->assign_valid = false;
+    }
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
-    if (!c->assign_valid) HIP_TRY(c, hipMemsetAsync(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_changed.p, 0, sizeof(int32_t), s));
-    memcpy(c->h_X.p, X, nx * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
-    if (c->tree_nodes > 0)
-        launch_route(c->d_X.p, c->n, c->dx, c->tree_dim, c->tree_wrap, c->d_tvec.p, c->d_tcenter.p, c->d_tsplit.p,
-                     c->d_tleft.p, c->d_tright.p, c->d_tleaf.p, c->d_assign.p, c->d_changed.p, s);
-    else
-        launch_assign(c->d_X.p, c->n, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, c->d_assign.p, c->d_changed.p, s);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_changed.p, c->d_changed.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    *changed = c->h_changed.p[0] ? 1 : 0;
-    if (!*changed) return GPRF_OK;
-    // somebody moved: bring the partition back and rebuild the unit tables from it, like a host re-blocking
-    HIP_TRY(c, hipMemcpy(c->h_assign.p, c->d_assign.p, (size_t)c->n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    int rc = gprf_set_block_assignment(c, c->n_centers, c->h_assign.p);
-    if (rc != GPRF_OK) { c->assign_valid = false; return rc; }
-    c->assign_valid = true;
-    if (block_of_out) memcpy(block_of_out, c->h_assign.p, (size_t)c->n * sizeof(int32_t));
-    return GPRF_OK;
+    int any_changed = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int rc = prepare(c, s);
+        if (rc != GPRF_OK) return rc;
+        memcpy(c->h_X.p, X, nx * sizeof(double));
+        HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+        rc = enqueue_partition(c, c->d_X.p, s);
+        if (rc != GPRF_OK) return rc;
+        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, s);
+        c->need_build = false;
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        int32_t rb = 0;
+        rc = absorb_control_words(c, true, &rb);
+        any_changed |= rb;
+        if (rc == GPRF_RETRY) continue;
+        if (rc != GPRF_OK) return rc;
+        *changed = any_changed;
+        if (any_changed && block_of_out) return fetch_assignment(c, block_of_out);
+        return GPRF_OK;
+    }
+    return fail(c, GPRF_ERR_STATE, "the unit tables did not fit the workspace after growing it twice");
+}
+
+int gprf_get_block_assignment(gprf_ctx *c, int32_t *block_of_out) {
+    if (!c || !block_of_out) return GPRF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return fetch_assignment(c, block_of_out);
 }
 
 int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
     if (!c || n_pairs < 0 || (n_pairs > 0 && !pairs_ij)) return GPRF_ERR_ARG;
     c->n_pairs = n_pairs;
     c->pairs.assign(pairs_ij, pairs_ij + 2 * (size_t)n_pairs);
-    c->units_dirty = true;
+    c->static_dirty = true;
     return GPRF_OK;
 }
 
@@ -840,7 +999,7 @@ int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return GPRF_ERR_ARG;
     c->rank = rank;
     c->world = world;
-    c->units_dirty = true;
+    c->static_dirty = true;
     return GPRF_OK;
 }
 
@@ -848,7 +1007,7 @@ int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
     if (!c) return GPRF_ERR_ARG;
     if (!jitter) {
         // the drivers clear the jitter before every evaluation (jitchol is stateless): clearing what is already
-        // clear must not cost a rebuild of the unit tables
+        // clear costs nothing
         if (c->unit_jitter.empty()) return GPRF_OK;
         c->unit_jitter.clear();
     } else {
@@ -857,7 +1016,7 @@ int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
             return GPRF_OK;
         c->unit_jitter.assign(jitter, jitter + n_units);
     }
-    c->units_dirty = true;
+    c->jitter_dirty = true;
     return GPRF_OK;
 }
 
@@ -868,15 +1027,28 @@ int gprf_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t
     if (!d_X || !d_out) return GPRF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    // table uploads in rebuild_units run on the context stream synchronously, so any stream may follow
-    return enqueue_eval(c, d_X, want_gradX, want_gradC, d_out, s, 6);
+    return enqueue_eval(c, d_X, want_gradX, want_gradC, d_out, s, 6, false);
+}
+
+int gprf_update_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
+                            void *stream) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (!d_X || !d_out) return GPRF_ERR_ARG;
+    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return enqueue_eval(c, d_X, want_gradX, want_gradC, d_out, s, 6, true);
 }
 
 int gprf_eval_status(gprf_ctx *c, int32_t *first_bad_unit) {
     if (!c) return GPRF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipDeviceSynchronize());
-    return finish_eval(c, c->stream, first_bad_unit);
+    if (!c->eval_pending) {
+        if (first_bad_unit) *first_bad_unit = -1;
+        return GPRF_OK;
+    }
+    return finish_eval(c, c->last_stream ? c->last_stream : c->stream, first_bad_unit, nullptr);
 }
 
 int gprf_eval(gprf_ctx *c, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
@@ -885,39 +1057,48 @@ int gprf_eval(gprf_ctx *c, const double *X, int32_t want_gradX, int32_t want_gra
     if (rc != GPRF_OK) return rc;
     if (!X || !ll_out || (want_gradX && !gradX_out) || (want_gradC && !gradC_out)) return GPRF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    size_t nx = (size_t)c->n * c->dx;
-    size_t nout = 1 + nx + c->ncov;
-    memcpy(c->h_X.p, X, nx * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
-    rc = enqueue_eval(c, c->d_X.p, want_gradX, want_gradC, c->d_out.p, s, 6);
+    return run_checked(c, X, want_gradX, want_gradC, ll_out, gradX_out, gradC_out, first_bad_unit, false, nullptr);
+}
+
+int gprf_update_eval(gprf_ctx *c, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
+                     double *gradX_out, double *gradC_out, int32_t *first_bad_unit, int32_t *reblocked) {
+    int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_out.p, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
-    rc = finish_eval(c, s, first_bad_unit);
-    if (rc != GPRF_OK) return rc;
-    *ll_out = c->h_out.p[0];
-    if (want_gradX) memcpy(gradX_out, c->h_out.p + 1, nx * sizeof(double));
-    if (want_gradC) memcpy(gradC_out, c->h_out.p + 1 + nx, c->ncov * sizeof(double));
-    return GPRF_OK;
+    if (!X || !ll_out || (want_gradX && !gradX_out) || (want_gradC && !gradC_out)) return GPRF_ERR_ARG;
+    if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_checked(c, X, want_gradX, want_gradC, ll_out, gradX_out, gradC_out, first_bad_unit, true, reblocked);
 }
 
 int gprf_num_units(const gprf_ctx *c, int32_t *n_total, int32_t *n_local) {
     if (!c) return GPRF_ERR_ARG;
     if (n_total) *n_total = c->n_blocks + c->n_pairs;
-    if (n_local) *n_local = c->units_dirty ? -1 : c->n_local;
+    if (n_local) *n_local = c->static_dirty ? -1 : c->n_local;
     return GPRF_OK;
 }
 
 int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
-    if (c->units_dirty) {
+    if (c->static_dirty) {
         HIP_TRY(c, hipSetDevice(c->device));
-        rc = rebuild_units(c);
+        rc = rebuild_static(c);
         if (rc != GPRF_OK) return rc;
     }
+    refresh_host_units(c);
     if (flops) *flops = c->work_flops;
     if (fill_bytes) *fill_bytes = c->work_fill_bytes;
+    return GPRF_OK;
+}
+
+int gprf_table_builds(gprf_ctx *c, int32_t *builds) {
+    if (!c || !builds) return GPRF_ERR_ARG;
+    *builds = 0;
+    if (!c->d_res.p) return GPRF_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(builds, res_ctl(c) + CTL_BUILDS, sizeof(int32_t), hipMemcpyDeviceToHost));
     return GPRF_OK;
 }
 
@@ -959,7 +1140,7 @@ int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
     memcpy(c->h_X.p, X, nx * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->last_stop_after = stop_after;
-    rc = enqueue_eval(c, c->d_X.p, 1, 1, c->d_out.p, c->stream, stop_after);
+    rc = enqueue_eval(c, c->d_X.p, 1, 1, c->d_out.p, c->stream, stop_after, false);
     if (rc != GPRF_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->eval_pending = false;
@@ -967,7 +1148,8 @@ int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
 }
 
 int gprf_debug_unit_shape(gprf_ctx *c, int32_t l, int32_t *m, int32_t *mp, int32_t *global_unit) {
-    if (!c || c->units_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
+    if (!c || c->static_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
+    refresh_host_units(c);
     if (m) *m = c->l_m[l];
     if (mp) *mp = pad16(c->l_m[l]);
     if (global_unit) *global_unit = c->l_global[l];
@@ -975,9 +1157,10 @@ int gprf_debug_unit_shape(gprf_ctx *c, int32_t l, int32_t *m, int32_t *mp, int32
 }
 
 int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t out_len) {
-    if (!c || !out || c->units_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
+    if (!c || !out || c->static_dirty || l < 0 || l >= c->n_local) return GPRF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    refresh_host_units(c);
     int64_t mp = pad16(c->l_m[l]);
     int64_t roff = c->l_rowoff[l];
     const double *src = nullptr;
@@ -1002,7 +1185,7 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
             int32_t info = 0;
             HIP_TRY(c, hipMemcpy(out + 1, c->d_logdet.p + l, sizeof(double), hipMemcpyDeviceToHost));
             HIP_TRY(c, hipMemcpy(zz, c->d_zzpart.p + (size_t)l * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(&info, c->d_info.p + l, sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&info, res_info(c) + l, sizeof(int32_t), hipMemcpyDeviceToHost));
             out[2] = (zz[0] + zz[1]) + (zz[2] + zz[3]);
             out[3] = info;
             out[0] = -0.5 * out[2] - 0.5 * c->dy * out[1] - 0.5 * c->dy * c->l_m[l] * std::log(2.0 * M_PI);
@@ -1023,6 +1206,13 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
             out[0] = 0.5 * g[0];
             out[1] = 0.5 * g[1] / c->theta[1];
             for (int t = 2; t < c->ncov; ++t) out[t] = 0.5 * g[t];
+            return GPRF_OK;
+        }
+        case 10: {  // the unit row -> point table of the unit (as doubles; rows >= m read -1)
+            if (out_len < mp) return GPRF_ERR_ARG;
+            std::vector<int32_t> r((size_t)std::max<int64_t>(mp, 1));
+            if (mp > 0) HIP_TRY(c, hipMemcpy(r.data(), c->d_upt.p + roff, (size_t)mp * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < mp; ++k) out[k] = k < c->l_m[l] ? (double)r[k] : -1.0;
             return GPRF_OK;
         }
         default: return GPRF_ERR_ARG;

@@ -22,20 +22,51 @@ struct KParams {
     int dx, ndfn, dy;
 };
 
-// Per-unit tables (device pointers), one entry per LOCAL unit.
+// Per-unit tables (device pointers), one entry per LOCAL unit.  m / row_off / mat_off / off_j / upt are written ON THE
+// DEVICE from the partition (k_unit_scan, k_place): nothing about a re-blocking returns to the host.
 struct UnitTab {
-    const int32_t *m;        // points in the unit
+    const int32_t *m;        // points in the unit (0 for every unit when the build overflowed the workspace: ctl)
     const int32_t *row_off;  // padded-row offset: sum of mp over previous units
     const int64_t *mat_off;  // element offset of the unit's mp x mp matrices in the U / W pools
     const double *weight;    // Bethe weight: 1 - deg(i) for unaries, 1 for pairs
     const double *jitter;    // extra diagonal (jitchol retry)
-    const int32_t *upt;      // [total padded rows] global point index of each unit row, -1 for padding
-    const int32_t *row_unit; // [total padded rows] local unit id of each padded row (filled on the device: k_row_unit)
-    const int32_t *ids;      // the local unit ids this launch covers (one stream group) ...
+    const int32_t *upt;      // [total padded rows] global point index of each unit row; rows >= m are NOT written
+    const int32_t *ids;      // the local unit ids in launch order (largest first at the last host build) ...
     int n_ids;               // ... and how many
     int n_units;
-    int max_T;               // max over units of mp/16
+    int max_T;               // launch-wide bound on mp/16 (the largest unit at the last synchronised build)
 };
+
+// What the device-side table build works from and leaves behind (all device pointers).
+struct BuildTab {
+    int32_t *assign;         // [n] block of every point, -1 = in no block
+    int32_t *posb;           // [n] position of the point inside its block
+    int32_t *rank;           // [n] scratch: position among the points of the same block within its 256-point chunk
+    int32_t *cnt;            // [n_chunks][n_blocks] points of a block per chunk -> (k_unit_scan) exclusive prefix over chunks
+    int32_t *bsize;          // [n_blocks] points per block
+    const int32_t *unit_bi;  // [n_local] first block of the unit
+    const int32_t *unit_bj;  // [n_local] second block, -1 for a unary unit
+    const int32_t *bu_ptr;   // [n_blocks + 1] CSR: block -> the local units that contain it, ascending unit id ...
+    const int32_t *bu_ent;   // ... as 2 * unit + side (side 1 = the block's rows come second in the unit)
+    int32_t *m;              // the UnitTab columns this build writes
+    int32_t *row_off;
+    int64_t *mat_off;
+    int32_t *off_j;          // [n_local] rows of the unit's first block (= where the second block's rows start)
+    int32_t *upt;
+    int32_t *ctl;            // control / result words, CTL_* below
+    int n, n_blocks, n_local, n_chunks;
+    int64_t cap_rows, cap_mat;   // workspace capacities the build must stay within
+    int maxT_bound;              // the launch-wide max_T the evaluation kernels will be launched with
+};
+constexpr int CTL_CHANGED = 0;     // some point changed block (set by k_assign / k_route)
+constexpr int CTL_OVERFLOW = 1;    // the partition does not fit the workspace / the launch bound: every unit got m = 0
+constexpr int CTL_ROWS = 2;        // total padded rows of the partition
+constexpr int CTL_MAXT = 3;        // its largest unit in tiles
+constexpr int CTL_MAXM = 4;        // ... in points
+constexpr int CTL_MAT_LO = 5;      // total matrix elements (64 bit, two words)
+constexpr int CTL_MAT_HI = 6;
+constexpr int CTL_BUILDS = 7;      // table builds since the context was created (tests)
+constexpr int CTL_WORDS = 8;
 
 // spare doubles behind the last unit's matrix in the U / W / K pools (row-panel loads address whole 64-column
 // chunks; the lanes beyond the unit's edge are masked off, the slack keeps even an unmasked variant in bounds)
@@ -49,9 +80,9 @@ struct Pools {
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
     double *Xu;    // gathered unit coordinates per padded row: XPAD doubles (euclidean) or the 8-double half-angle
                    // record of the lld distance (k_gather_x)
-    double *Yu;    // gathered unit outputs, YPAD per padded row (zero padded)
-    double *Z;     // U^-T Yu, YPAD per padded row
-    double *At;    // (K^-1 Yu)^T : per unit YPAD x mp at YPAD*row_off
+    const double *Y;  // the outputs, n x dy row-major (gathered through upt where a kernel needs unit rows)
+    double *Z;     // U^-T Y[unit rows], YPAD per padded row
+    double *At;    // (K^-1 Y[unit rows])^T : per unit YPAD x mp at YPAD*row_off
     double *gXu;   // per-unit-row gradient slab, XPAD per padded row
     double *rowpart;  // k_mgrad: per padded row, TBm x XPAD partial row sums (one per column block JB <= its block)
     double *colpart;  // k_mgrad: per padded row, TBm x XPAD partial column sums (one per row block IB >= its block)
@@ -63,27 +94,34 @@ struct Pools {
 };
 
 struct AssembleTab {
-    const int64_t *slot_ptr;   // [n+1]
-    const int32_t *slot_row;   // padded-row index into gXu (the slot's weight is its unit's: weight[row_unit[row]])
+    const int32_t *assign;     // [n] block of every point
+    const int32_t *posb;       // [n] its position inside the block
+    const int32_t *bu_ptr;     // block -> local units CSR (BuildTab)
+    const int32_t *bu_ent;
+    const int32_t *off_j;
+    const int32_t *ctl;
 };
 
-void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+// re-blocking: nearest centre / split-tree descent of every point, with the per-chunk ranks and counts the table
+// build starts from (bt.assign / rank / cnt / ctl[CTL_CHANGED])
+void launch_assign(const double *X, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt, hipStream_t s);
+void launch_route(const double *X, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
-                  int32_t *block_of, int32_t *changed, hipStream_t s);
-void launch_row_unit(const UnitTab &ut, int32_t *row_unit, hipStream_t s);
-void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s);
-void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s);
+                  const BuildTab &bt, hipStream_t s);
+// unit tables from the partition: sizes, offsets (k_unit_scan), unit row -> point (k_place).  from_chunks: the partition
+// came from launch_assign / launch_route (ranks + per-chunk counts), otherwise bt.posb / bt.bsize were uploaded.
+// force = 0: only when ctl[CTL_CHANGED] is set.
+void launch_build_tables(const BuildTab &bt, int from_chunks, int force, hipStream_t s);
+void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
 void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s);
-void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s);
+void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 int total_rows, bool have_K, hipStream_t s);
+                 bool have_K, hipStream_t s);
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
-void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s);
-void launch_assign(const double *X, int n, int dx, const double *cs, const double *c2, int nc, int32_t *block_of,
-                   int32_t *changed, hipStream_t s);
 
 }  // namespace gprf

@@ -245,38 +245,35 @@ template <int DIST> struct PtRec { static constexpr int STRIDE = XPAD, NREG = 3;
 template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = GEO_N; };
 
 // ------------------------------------------------------------------------------------------------
-// gathers (gprf.py:300-302, 314-326: X[idxs], Y[idxs], vstack) into padded per-unit rows
+// gathers (gprf.py:300-302, 314-326: X[idxs], Y[idxs], vstack) into padded per-unit rows.  The coordinates are
+// gathered once per evaluation (k_gather_x, one workgroup per unit: rows >= m are padding and get zeros; upt is
+// only defined below m); the outputs never move: the one kernel that needs a unit's Y rows (the forward
+// substitution) reads them through upt from the resident n x dy array, which stays in L2 / the Infinity Cache.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_gather_y(const int32_t *__restrict__ upt, const double *__restrict__ Y, double *__restrict__ Yu,
-                           int dy, int total_rows) {
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int c = threadIdx.x & 63;
-    if (row >= total_rows) return;
-    int pt = upt[row];
-    double v = 0.0;
-    if (pt >= 0 && c < dy) v = Y[(size_t)pt * dy + c];
-    Yu[(size_t)row * YPAD + c] = v;
-}
-
-__global__ void k_gather_x(const int32_t *__restrict__ upt, const double *__restrict__ X, double *__restrict__ Xu,
-                           int dx, int total_rows, int geo) {
-    int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= total_rows) return;
-    int pt = upt[row];
-    if (geo) {
-        // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
-        double lon = 0.0, lat = 0.0, z = 0.0;
-        if (pt >= 0) { lon = X[(size_t)pt * dx]; lat = X[(size_t)pt * dx + 1]; z = X[(size_t)pt * dx + 2]; }
-        double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
-        double *g = Xu + (size_t)row * GEO_STRIDE;
-        g[GEO_SLH] = sin(hl); g[GEO_CLH] = cos(hl); g[GEO_SNH] = sin(hn); g[GEO_CNH] = cos(hn); g[GEO_Z] = z;
-        g[5] = 0.0; g[6] = 0.0; g[7] = 0.0;
-        return;
-    }
-    for (int d = 0; d < XPAD; ++d) {
-        double v = 0.0;
-        if (pt >= 0 && d < dx) v = X[(size_t)pt * dx + d];
-        Xu[(size_t)row * XPAD + d] = v;
+__global__ __launch_bounds__(256) void k_gather_x(UnitTab ut, const double *__restrict__ X, double *__restrict__ Xu,
+                                                  int dx, int geo) {
+    int u = blockIdx.x;
+    int m = ut.m[u];
+    int mp = pad16(m);
+    int r0 = ut.row_off[u];
+    for (int r = threadIdx.x; r < mp; r += 256) {
+        int row = r0 + r;
+        int pt = r < m ? ut.upt[row] : -1;
+        if (geo) {
+            // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
+            double lon = 0.0, lat = 0.0, z = 0.0;
+            if (pt >= 0) { lon = X[(size_t)pt * dx]; lat = X[(size_t)pt * dx + 1]; z = X[(size_t)pt * dx + 2]; }
+            double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
+            double *g = Xu + (size_t)row * GEO_STRIDE;
+            g[GEO_SLH] = sin(hl); g[GEO_CLH] = cos(hl); g[GEO_SNH] = sin(hn); g[GEO_CNH] = cos(hn); g[GEO_Z] = z;
+            g[5] = 0.0; g[6] = 0.0; g[7] = 0.0;
+            continue;
+        }
+        for (int d = 0; d < XPAD; ++d) {
+            double v = 0.0;
+            if (pt >= 0 && d < dx) v = X[(size_t)pt * dx + d];
+            Xu[(size_t)row * XPAD + d] = v;
+        }
     }
 }
 
@@ -1285,7 +1282,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 constexpr int SOLVE_WAVES = 4;
 constexpr int SOLVE_SLOTS = MAX_T / SOLVE_WAVES;  // 8
 
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl, int dy) {
     __shared__ double Wr[2][256];
     __shared__ double zred[SOLVE_WAVES];
     int u = ut.ids[blockIdx.y];
@@ -1306,7 +1303,7 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
     const double *V = pl.V + roff * 16;
     double *W = pl.W + ut.mat_off[u];
     double *Z = pl.Z + roff * YPAD;
-    const double *Yu = pl.Yu + roff * YPAD;
+    const int32_t *upt = ut.upt + roff;
     int r0 = is_y ? 0 : cb;
 
     d4 acc[SOLVE_SLOTS];
@@ -1317,8 +1314,12 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
         for (int q = 0; q < 4; ++q) {
             double v = 0.0;
             if (r < T) {
-                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
-                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+                if (is_y) {
+                    int row = 16 * r + lg + 4 * q, col = 16 * cb + lr;     // Y[unit rows]: gathered here, zero padded
+                    if (row < m && col < dy) v = pl.Y[(size_t)upt[row] * dy + col];
+                } else {
+                    v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+                }
             }
             acc[sl][q] = v;
         }
@@ -1390,7 +1391,7 @@ constexpr int SOLVE_PANEL_MAXT = 28;  // largest k_solve_panel instantiation (ac
 // Each wave's tiles for all rows stay in MFMA accumulators; the freshly solved tile is already in B-operand layout
 // (accumulator register q = rows 4q+lg), so the right-looking updates chain through registers.
 template <int MAXT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, int dy) {
     constexpr int LDP = 16 * MAXT + 16;          // (LDP/16) odd: lane groups 32 banks apart
     constexpr int NCH = (16 * MAXT + 63) / 64;
     __shared__ double panel[2][16 * LDP];
@@ -1419,7 +1420,8 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
     const double *__restrict__ V = pl.V + roff * 16;
     double *__restrict__ W = pl.W + ut.mat_off[u];
     double *__restrict__ Z = pl.Z + roff * YPAD;
-    const double *__restrict__ Yu = pl.Yu + roff * YPAD;
+    const int32_t *__restrict__ upt = ut.upt + roff;
+    const double *__restrict__ Yg = pl.Y;
     int r0 = is_y ? 0 : cb;
 
     // (static_for, not "#pragma unroll": the optimizer gives up on the 28-tile instantiation's loops and the
@@ -1431,8 +1433,12 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl) 
         for (int q = 0; q < 4; ++q) {
             double v = 0.0;
             if (live && r >= r0 && r < T) {
-                if (is_y) v = Yu[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr];
-                else v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+                if (is_y) {
+                    int row = 16 * r + lg + 4 * q, col = 16 * cb + lr;     // Y[unit rows]: gathered here, zero padded
+                    if (row < m && col < dy) v = Yg[(size_t)upt[row] * dy + col];
+                } else {
+                    v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+                }
             }
             acc[r][q] = v;
         }
@@ -2037,7 +2043,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-            if (lg == 0) red[wave][16 * jj + lr][d] = csum[jj][d];
+            if (lg == 0) red[wrow][16 * jj + lr][d] = csum[jj][d];      // by ROW TILE, not by wave: the fold below must
+                                                                        // not depend on the launch-dependent rotation
     // row sums of this wave's 16 rows over the block's 64 columns -> rowpart[row][JB]
     if (active) {
 #pragma unroll
@@ -2071,7 +2078,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     }
     if (lane == 0) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) gcred[wave][t] = gcv[t];
+        for (int t = 0; t < 5; ++t) gcred[wrow][t] = gcv[t];
     }
     GPRF_MST(3)
     __syncthreads();
@@ -2120,21 +2127,24 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
 
 // gXu[row] = sum_{IB >= B} colpart[row][IB] + sum_{JB <= B} rowpart[row][JB],  B = the row's 64-point block
 // (fixed order -> bit-reproducible)
-__global__ void k_gx_finalize(UnitTab ut, Pools pl, int total_rows) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int row = idx >> 2, d = idx & 3;
-    if (row >= total_rows || d == 3) return;
-    int u = ut.row_unit[row];
-    int local = row - ut.row_off[u];
-    int B = local >> 6;
-    int TB = ((pad16(ut.m[u]) >> 4) + 3) >> 2;
+__global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl) {
+    int u = blockIdx.x;
+    int mp = pad16(ut.m[u]);
+    int r0 = ut.row_off[u];
+    int TB = ((mp >> 4) + 3) >> 2;
     int tbs = (ut.max_T + 3) >> 2;
-    const double *cp = pl.colpart + (size_t)row * tbs * XPAD + d;
-    const double *rp = pl.rowpart + (size_t)row * tbs * XPAD + d;
-    double v = 0.0;
-    for (int IB = B; IB < TB; ++IB) v += cp[IB * XPAD];
-    for (int JB = 0; JB <= B; ++JB) v += rp[JB * XPAD];
-    pl.gXu[(size_t)row * XPAD + d] = v;
+    for (int idx = threadIdx.x; idx < 4 * mp; idx += 256) {
+        int local = idx >> 2, d = idx & 3;
+        if (d == 3) continue;
+        int row = r0 + local;
+        int B = local >> 6;
+        const double *cp = pl.colpart + (size_t)row * tbs * XPAD + d;
+        const double *rp = pl.rowpart + (size_t)row * tbs * XPAD + d;
+        double v = 0.0;
+        for (int IB = B; IB < TB; ++IB) v += cp[IB * XPAD];
+        for (int JB = 0; JB <= B; ++JB) v += rp[JB * XPAD];
+        pl.gXu[(size_t)row * XPAD + d] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2191,11 +2201,16 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
     if (idx >= (long)n * dx) return;
     int p = (int)(idx / dx), d = (int)(idx % dx);
     double v = 0.0;
-    if (want_gx) {
-        for (int64_t s = at.slot_ptr[p]; s < at.slot_ptr[p + 1]; ++s)
-        {
-            int row = at.slot_row[s];
-            v += ut.weight[ut.row_unit[row]] * pl.gXu[(size_t)row * XPAD + d];
+    int b = at.assign[p];
+    if (want_gx && b >= 0 && !at.ctl[CTL_OVERFLOW]) {
+        // the point's rows: position posb[p] of its block inside every local unit that contains the block, in
+        // ascending unit order (gprf.py:258-273: unary term first, then the pair terms in neighbour order)
+        int pos = at.posb[p];
+        for (int e = at.bu_ptr[b]; e < at.bu_ptr[b + 1]; ++e) {
+            int ent = at.bu_ent[e];
+            int u = ent >> 1;
+            int row = ut.row_off[u] + ((ent & 1) ? at.off_j[u] : 0) + pos;
+            v += ut.weight[u] * pl.gXu[(size_t)row * XPAD + d];
         }
     }
     out[1 + idx] = v;
@@ -2230,116 +2245,243 @@ static int device_cus() {
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
 
 // ------------------------------------------------------------------------------------------------
-// k_assign: nearest cluster centre of every point (the re-blocking the reference's drivers do before each
-// evaluation, block_clustering.py:4-5,15-17 via gprf.py:171-172), one thread per point, the centres (structure of
-// arrays + squared norms) read wave-uniformly.  Same arithmetic as the host helper gprf_nearest_center — radicand
-// x2 - 2 x.c + c2 accumulated in the same order with no FMA contraction, a negative radicand (NaN distance) wins
-// first, otherwise the first minimum — so the two agree bit for bit.  A point that changes block raises *changed.
+// Re-blocking on the device (gprf.py:169-174: update_X re-runs block_fn before every evaluation).
+//
+// partition_tail: what both partition kernels (nearest centre, split tree) end with.  One workgroup = one chunk of
+// 256 consecutive points.  Besides the new block of its point each thread leaves
+//   rank[p]       = points of the same block earlier in the chunk,
+//   cnt[chunk][b] = points of block b in the chunk (written by the block's last point of the chunk; zeroed before),
+// from which k_unit_scan / k_place derive every table — the points of a block keep ascending index order, exactly
+// `all_idxs[blocks == i]` (block_clustering.py:21-24).  A point that changes block raises ctl[CTL_CHANGED].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, int n, int dx, const double *__restrict__ cs,
-                                                const double *__restrict__ c2, int nc, int32_t *__restrict__ block_of,
-                                                int32_t *__restrict__ changed) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void partition_tail(int p, int n, int best, const BuildTab &bt, int *keys /* LDS [256] */) {
+    int t = threadIdx.x;
+    keys[t] = p < n ? best : -1;
+    __syncthreads();
     if (p >= n) return;
-    double x[8], x2 = 0.0;
-    for (int d = 0; d < dx; ++d) {
-        x[d] = X[(size_t)p * dx + d];
-        x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
+    int before = 0, total = 0;
+    for (int q = 0; q < 256; ++q) {
+        int same = keys[q] == best ? 1 : 0;      // (wave-uniform address: LDS broadcast)
+        total += same;
+        before += (q < t) ? same : 0;
     }
+    bt.rank[p] = before;
+    if (before == total - 1) bt.cnt[(size_t)blockIdx.x * bt.n_blocks + best] = total;
+    if (bt.assign[p] != best) {
+        bt.assign[p] = best;
+        bt.ctl[CTL_CHANGED] = 1;            // benign race: every writer stores the same value
+    }
+}
+
+// k_assign: nearest cluster centre of every point (block_clustering.py:4-5,15-17), one thread per point, the centres
+// (structure of arrays + squared norms) read wave-uniformly.  Same arithmetic as the host helper gprf_nearest_center
+// — radicand x2 - 2 x.c + c2 accumulated in the same order with no FMA contraction, a negative radicand (NaN distance)
+// wins first, otherwise the first minimum — so the two agree bit for bit.
+__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, int dx, const double *__restrict__ cs,
+                                                const double *__restrict__ c2, int nc, BuildTab bt) {
+    __shared__ int keys[256];
+    int n = bt.n;
+    int p = blockIdx.x * 256 + threadIdx.x;
     int best = 0;
-    double bestv = 0.0;
-    bool best_nan = false;
-    for (int k = 0; k < nc && !best_nan; ++k) {
-        double r = 0.0;
-        for (int d = 0; d < dx; ++d) r = __dadd_rn(r, __dmul_rn(x[d], cs[(size_t)d * nc + k]));
-        double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2[k]);
-        if (k == 0) {
-            bestv = v;
-            best_nan = v < 0.0;
-        } else if (v < 0.0) {
-            best = k;
-            best_nan = true;
-        } else if (v < bestv) {
-            best = k;
-            bestv = v;
+    if (p < n) {
+        double x[8], x2 = 0.0;
+        for (int d = 0; d < dx; ++d) {
+            x[d] = X[(size_t)p * dx + d];
+            x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
+        }
+        double bestv = 0.0;
+        bool best_nan = false;
+        for (int k = 0; k < nc && !best_nan; ++k) {
+            double r = 0.0;
+            for (int d = 0; d < dx; ++d) r = __dadd_rn(r, __dmul_rn(x[d], cs[(size_t)d * nc + k]));
+            double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2[k]);
+            if (k == 0) {
+                bestv = v;
+                best_nan = v < 0.0;
+            } else if (v < 0.0) {
+                best = k;
+                best_nan = true;
+            } else if (v < bestv) {
+                best = k;
+                bestv = v;
+            }
         }
     }
-    if (block_of[p] != best) {
-        block_of[p] = best;
-        *changed = 1;            // benign race: every writer stores the same value
-    }
+    partition_tail(p, n, best, bt, keys);
 }
 
-void launch_assign(const double *X, int n, int dx, const double *cs, const double *c2, int nc, int32_t *block_of,
-                   int32_t *changed, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, s, X, n, dx, cs, c2, nc, block_of, changed);
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_route: the seismic driver's re-blocking (pdtree_clustering.py:65-94 via gprf.py:171-172): every point descends
 // the principal-direction tree — (x - center_k) . vec_k < split_k ? left : right — one thread per point, the
 // longitude first moved to [-22, 338) like the reference's `(lon + 22) % 360 - 22`.  The projection is accumulated
 // column by column with separately rounded multiplies and adds, which is how gprf_amd/seismic.py builds and routes
 // (numpy element-wise ops): bit-identical decisions, including the median point whose projection equals the split.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, int n, int dx, int dim, int lon_wrap,
+__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, int dx, int dim, int lon_wrap,
                                                const double *__restrict__ vec, const double *__restrict__ center,
                                                const double *__restrict__ split, const int32_t *__restrict__ left,
                                                const int32_t *__restrict__ right, const int32_t *__restrict__ leaf_block,
-                                               int32_t *__restrict__ block_of, int32_t *__restrict__ changed) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    double x[8];
-    for (int d = 0; d < dim; ++d) x[d] = X[(size_t)p * dx + d];
-    if (lon_wrap) {
-        double r = fmod(__dadd_rn(x[0], 22.0), 360.0);          // numpy's %: the result takes the divisor's sign
-        if (r != 0.0) { if (r < 0.0) r = __dadd_rn(r, 360.0); } else r = 0.0;
-        x[0] = __dsub_rn(r, 22.0);
+                                               BuildTab bt) {
+    __shared__ int keys[256];
+    int n = bt.n;
+    int p = blockIdx.x * 256 + threadIdx.x;
+    int best = 0;
+    if (p < n) {
+        double x[8];
+        for (int d = 0; d < dim; ++d) x[d] = X[(size_t)p * dx + d];
+        if (lon_wrap) {
+            double r = fmod(__dadd_rn(x[0], 22.0), 360.0);          // numpy's %: the result takes the divisor's sign
+            if (r != 0.0) { if (r < 0.0) r = __dadd_rn(r, 360.0); } else r = 0.0;
+            x[0] = __dsub_rn(r, 22.0);
+        }
+        int k = 0;
+        while (left[k] >= 0) {
+            double a = __dmul_rn(__dsub_rn(x[0], center[(size_t)k * dim]), vec[(size_t)k * dim]);
+            for (int d = 1; d < dim; ++d)
+                a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
+            k = (a < split[k]) ? left[k] : right[k];
+        }
+        best = leaf_block[k];
     }
-    int k = 0;
-    while (left[k] >= 0) {
-        double a = __dmul_rn(__dsub_rn(x[0], center[(size_t)k * dim]), vec[(size_t)k * dim]);
-        for (int d = 1; d < dim; ++d)
-            a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
-        k = (a < split[k]) ? left[k] : right[k];
-    }
-    int best = leaf_block[k];
-    if (block_of[p] != best) {
-        block_of[p] = best;
-        *changed = 1;            // benign race: every writer stores the same value
-    }
+    partition_tail(p, n, best, bt, keys);
 }
 
-void launch_route(const double *X, int n, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+void launch_assign(const double *X, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt, hipStream_t s) {
+    if (bt.n == 0) return;
+    hipLaunchKernelGGL(k_assign, dim3(bt.n_chunks), dim3(256), 0, s, X, dx, cs, c2, nc, bt);
+}
+
+void launch_route(const double *X, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
-                  int32_t *block_of, int32_t *changed, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_route, dim3((n + 255) / 256), dim3(256), 0, s, X, n, dx, dim, lon_wrap, vec, center, split, left,
-                       right, leaf_block, block_of, changed);
+                  const BuildTab &bt, hipStream_t s) {
+    if (bt.n == 0) return;
+    hipLaunchKernelGGL(k_route, dim3(bt.n_chunks), dim3(256), 0, s, X, dx, dim, lon_wrap, vec, center, split, left,
+                       right, leaf_block, bt);
 }
 
-// row -> unit table, written on the device at every re-blocking (a third of a megabyte less to upload)
-__global__ void k_row_unit(UnitTab ut, int32_t *__restrict__ row_unit) {
-    int l = blockIdx.x;
-    int mp = pad16(ut.m[l]), r0 = ut.row_off[l];
-    for (int r = threadIdx.x; r < mp; r += blockDim.x) row_unit[r0 + r] = l;
+// ------------------------------------------------------------------------------------------------
+// k_unit_scan (ONE workgroup): the unit tables from the partition.
+//   (a) from_chunks: per block, the exclusive prefix of cnt over the chunks (in place) and the block size;
+//   (b) per local unit: m = |block i| (+ |block j|), off_j = |block i|, and the running offsets row_off = sum mp,
+//       mat_off = sum mp^2 (mp = m rounded up to 16) — what rebuild_units did on the host (gprf.py:236-239 order);
+//   (c) the totals, checked against the workspace the host reserved and the max_T the evaluation's kernels will be
+//       launched with: on overflow every unit gets m = 0 (each kernel then has nothing to do) and ctl says so; the
+//       host grows the workspace and repeats the evaluation.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 1024;
+
+// exclusive prefix sums of a (int64) and b (int64) over the workgroup; returns the totals through ta / tb
+__device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long *sh /* LDS [2][16] */, long long *ta,
+                                           long long *tb) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long ia = a, ib = b;
+    for (int off = 1; off < 64; off <<= 1) {
+        long long ua = __shfl_up(ia, off, 64), ub = __shfl_up(ib, off, 64);
+        if (lane >= off) { ia += ua; ib += ub; }
+    }
+    if (lane == 63) { sh[wave] = ia; sh[16 + wave] = ib; }
+    __syncthreads();
+    long long pa = 0, pb = 0, sa = 0, sb = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        if (w < wave) { pa += sh[w]; pb += sh[16 + w]; }
+        sa += sh[w]; sb += sh[16 + w];
+    }
+    __syncthreads();
+    a = pa + ia - a;
+    b = pb + ib - b;
+    *ta = sa;
+    *tb = sb;
 }
 
-void launch_row_unit(const UnitTab &ut, int32_t *row_unit, hipStream_t s) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_unit_scan(BuildTab bt, int from_chunks, int force) {
+    __shared__ long long sh[32];
+    __shared__ int s_maxm;
+    if (!force && !bt.ctl[CTL_CHANGED]) return;
+    int t = threadIdx.x;
+    if (t == 0) s_maxm = 0;
+    if (from_chunks) {
+        for (int b = t; b < bt.n_blocks; b += SCAN_THREADS) {
+            int run = 0;
+            for (int c = 0; c < bt.n_chunks; ++c) {
+                int *e = bt.cnt + (size_t)c * bt.n_blocks + b;
+                int v = *e;
+                *e = run;
+                run += v;
+            }
+            bt.bsize[b] = run;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    long long rows = 0, mat = 0;
+    for (int l0 = 0; l0 < bt.n_local; l0 += SCAN_THREADS) {
+        int l = l0 + t;
+        int m = 0, mi = 0;
+        if (l < bt.n_local) {
+            mi = bt.bsize[bt.unit_bi[l]];
+            int bj = bt.unit_bj[l];
+            m = mi + (bj >= 0 ? bt.bsize[bj] : 0);
+        }
+        long long mp = (m + 15) & ~15;
+        long long a = mp, b = mp * mp, ta, tb;
+        wg_exscan2(a, b, sh, &ta, &tb);
+        if (l < bt.n_local) {
+            bt.m[l] = m;
+            bt.off_j[l] = mi;
+            bt.row_off[l] = (int32_t)(rows + a);
+            bt.mat_off[l] = mat + b;
+            atomicMax(&s_maxm, m);
+        }
+        rows += ta;
+        mat += tb;
+    }
+    __syncthreads();
+    int maxm = s_maxm;
+    int maxT = ((maxm + 15) & ~15) >> 4;
+    bool over = rows > bt.cap_rows || mat > bt.cap_mat || maxT > bt.maxT_bound || maxm > MAX_MP;
+    if (over)
+        for (int l = t; l < bt.n_local; l += SCAN_THREADS) { bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0; }
+    if (t == 0) {
+        bt.ctl[CTL_OVERFLOW] = over ? 1 : 0;
+        bt.ctl[CTL_ROWS] = (int32_t)rows;
+        bt.ctl[CTL_MAXT] = maxT;
+        bt.ctl[CTL_MAXM] = maxm;
+        bt.ctl[CTL_MAT_LO] = (int32_t)(mat & 0xffffffffll);
+        bt.ctl[CTL_MAT_HI] = (int32_t)(mat >> 32);
+        bt.ctl[CTL_BUILDS] += 1;
+    }
+}
+
+// k_place: position of every point inside its block and its rows in the unit row -> point table: the point sits at
+// position posb of its block in every local unit that contains the block (rows of block j after block i's,
+// gprf.py:322-326).
+__global__ __launch_bounds__(256) void k_place(BuildTab bt, int from_chunks, int force) {
+    if (!force && !bt.ctl[CTL_CHANGED]) return;
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= bt.n) return;
+    int b = bt.assign[p];
+    if (b < 0) return;
+    int pos;
+    if (from_chunks) {
+        pos = bt.cnt[(size_t)blockIdx.x * bt.n_blocks + b] + bt.rank[p];
+        bt.posb[p] = pos;
+    } else {
+        pos = bt.posb[p];
+    }
+    if (bt.ctl[CTL_OVERFLOW]) return;
+    for (int e = bt.bu_ptr[b]; e < bt.bu_ptr[b + 1]; ++e) {
+        int ent = bt.bu_ent[e];
+        int u = ent >> 1;
+        bt.upt[bt.row_off[u] + ((ent & 1) ? bt.off_j[u] : 0) + pos] = p;
+    }
+}
+
+void launch_build_tables(const BuildTab &bt, int from_chunks, int force, hipStream_t s) {
+    hipLaunchKernelGGL(k_unit_scan, dim3(1), dim3(SCAN_THREADS), 0, s, bt, from_chunks, force);
+    if (bt.n > 0) hipLaunchKernelGGL(k_place, dim3(bt.n_chunks), dim3(256), 0, s, bt, from_chunks, force);
+}
+
+void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, hipStream_t s) {
     if (ut.n_units == 0) return;
-    hipLaunchKernelGGL(k_row_unit, dim3(ut.n_units), dim3(64), 0, s, ut, row_unit);
-}
-
-void launch_gather_y(const UnitTab &ut, const Pools &p, const double *Y, int dy, int total_rows, hipStream_t s) {
-    if (total_rows == 0) return;
-    hipLaunchKernelGGL(k_gather_y, dim3((total_rows + 3) / 4), dim3(256), 0, s, ut.upt, Y, p.Yu, dy, total_rows);
-}
-
-void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, int total_rows, hipStream_t s) {
-    if (total_rows == 0) return;
-    hipLaunchKernelGGL(k_gather_x, dim3((total_rows + 255) / 256), dim3(256), 0, s, ut.upt, X, p.Xu, dx, total_rows,
-                       dist_id == 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_gather_x, dim3(ut.n_units), dim3(256), 0, s, ut, X, p.Xu, dx, dist_id == 1 ? 1 : 0);
 }
 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
@@ -2402,17 +2544,17 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, stamps, reg_maxT);
 }
 
-void launch_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
+void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0) return;
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
         dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
-        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve_panel<12, 3>), grid, dim3(256), 0, s, ut, p);
-        else if (ut.max_T <= 18) hipLaunchKernelGGL((k_solve_panel<18, 2>), grid, dim3(256), 0, s, ut, p);
-        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1>), grid, dim3(256), 0, s, ut, p);
+        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve_panel<12, 3>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        else if (ut.max_T <= 18) hipLaunchKernelGGL((k_solve_panel<18, 2>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
         return;
     }
-    // units of more than 288 points: accumulators no longer fit the register budget -> LDS-broadcast form
-    hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_ids), dim3(SOLVE_WAVES * 64), 0, s, ut, p);
+    // units of more than 448 points: accumulators no longer fit the register budget -> LDS-broadcast form
+    hipLaunchKernelGGL(k_solve, dim3(ut.max_T + 4, ut.n_ids), dim3(SOLVE_WAVES * 64), 0, s, ut, p, kp.dy);
 }
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
@@ -2428,14 +2570,13 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
         hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
 }
 
-void launch_gx_finalize(const UnitTab &ut, const Pools &p, int total_rows, hipStream_t s) {
-    if (total_rows == 0) return;
-    hipLaunchKernelGGL(k_gx_finalize, dim3((total_rows * 4 + 255) / 256), dim3(256), 0, s, ut, p, total_rows);
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s) {
+    if (ut.n_units == 0) return;
+    hipLaunchKernelGGL(k_gx_finalize, dim3(ut.n_units), dim3(256), 0, s, ut, p);
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
-                 int total_rows, bool have_K, hipStream_t s) {
-    (void)total_rows;
+                 bool have_K, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     int TBm = (ut.max_T + 3) / 4;
     dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));

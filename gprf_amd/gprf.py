@@ -55,6 +55,7 @@ class GPRF(object):
         self.Y = Y
         self._block_idxs = None
         self._block_of = None
+        self._reblock_pending = False
         if block_idxs is None:
             block_idxs = block_fn(X)
         self.block_idxs = block_idxs
@@ -94,12 +95,21 @@ class GPRF(object):
 
     @property
     def block_idxs(self):
-        """list of index arrays (gprf.py:100); built lazily after a library-side re-blocking"""
+        """list of index arrays (gprf.py:100); after a re-blocking on the device it is fetched (and the re-blocking
+        itself run, if update_X has only announced it) when somebody reads it"""
+        if self._reblock_pending:
+            # update_X was called but no evaluation has happened yet: partition now (what block_fn(new_X) would return)
+            changed, block_of = self._ctx.assign_blocks(np.ascontiguousarray(self.X, dtype=np.float64))
+            self._reblock_pending = False
+            if changed:
+                self._block_of, self._block_idxs = block_of, None
         if self._block_idxs is None:
+            if self._block_of is None:
+                self._block_of = self._ctx.get_block_assignment()
             order = np.argsort(self._block_of, kind="stable")
             counts = np.bincount(self._block_of, minlength=self.n_blocks)
             self._block_idxs = np.split(order, np.cumsum(counts)[:-1])
-            if self._blocks_pushed == "assignment":
+            if self._blocks_pushed == "device":
                 self._blocks_pushed = self._block_idxs      # the library already holds exactly this partition
         return self._block_idxs
 
@@ -107,9 +117,10 @@ class GPRF(object):
     def block_idxs(self, v):
         self._block_idxs = v
         self._block_of = None
+        self._reblock_pending = False
 
     def _push_blocks(self):
-        if self._blocks_pushed == "assignment" and self._block_idxs is None:
+        if self._blocks_pushed == "device" and self._block_idxs is None:
             return
         if self._blocks_pushed is self._block_idxs:
             return
@@ -153,42 +164,41 @@ class GPRF(object):
         self.noise_var = nv
         self._push_theta()
 
+    def _device_router(self):
+        """The object whose partition rule the library can evaluate itself: a grid ``Blocker`` (block_fn is its
+        ``block_clusters``) or the split tree behind ``seismic.pdtree_cluster``'s ``reblock``; None otherwise."""
+        fn = self.block_fn
+        if fn is None:
+            return None
+        from .blocking import Blocker
+        blocker = getattr(fn, "__self__", None)
+        tree = getattr(fn, "tree", None)
+        if isinstance(blocker, Blocker) and getattr(fn, "__name__", "") == "block_clusters" \
+                and blocker.n_blocks == self.n_blocks:
+            if getattr(self, "_centers_of", None) is not blocker:
+                self._ctx.set_centers(blocker.block_centers)
+                self._centers_of = blocker
+            return blocker
+        if tree is not None and hasattr(tree, "leaf_block") and len(tree.leaf_order) == self.n_blocks:
+            if getattr(self, "_centers_of", None) is not tree:
+                self._ctx.set_split_tree(tree.vec, tree.center, tree.split, tree.left, tree.right, tree.leaf_block,
+                                         getattr(fn, "lon_wrap", False))
+                self._centers_of = tree
+            return tree
+        return None
+
     def update_X(self, new_X, update_blocks=True, recompute_neighbors=False):
         """gprf.py:169-174: rebinding X re-runs block_fn on every call; the neighbour list stays.
 
-        When ``block_fn`` is the ``block_clusters`` method of a grid ``Blocker`` the assignment runs in the C
-        library (gprf_set_centers + gprf_assign_blocks) and ``block_idxs`` is materialised only if somebody reads
-        it; the same for the ``reblock`` of ``seismic.pdtree_cluster`` (gprf_set_split_tree)."""
+        When ``block_fn`` is the ``block_clusters`` method of a grid ``Blocker`` (or the ``reblock`` of
+        ``seismic.pdtree_cluster``) the library evaluates the partition rule itself, on the device, as the first step of
+        the NEXT evaluation (``gprf_update_eval``: one upload of X, re-partition, unit tables rebuilt on the device if
+        anybody changed block, evaluation, one download); ``block_idxs`` is fetched only if somebody reads it."""
         self.X = new_X
         if self.block_fn is not None:
-            blocker = getattr(self.block_fn, "__self__", None)
-            tree = getattr(self.block_fn, "tree", None)
-            from .blocking import Blocker
-            device_route = None
-            if isinstance(blocker, Blocker) and getattr(self.block_fn, "__name__", "") == "block_clusters" \
-                    and blocker.n_blocks == self.n_blocks:
-                # nearest-centre assignment on the device; the partition comes back to the host (and the unit
-                # tables are rebuilt) only when some point changed block
-                if getattr(self, "_centers_of", None) is not blocker:
-                    self._ctx.set_centers(blocker.block_centers)
-                    self._centers_of = blocker
-                device_route = blocker
-            elif tree is not None and hasattr(tree, "leaf_block") and len(tree.leaf_order) == self.n_blocks:
-                # seismic.pdtree_cluster's reblock: the same, descending the split tree on the device
-                if getattr(self, "_centers_of", None) is not tree:
-                    self._ctx.set_split_tree(tree.vec, tree.center, tree.split, tree.left, tree.right, tree.leaf_block,
-                                             getattr(self.block_fn, "lon_wrap", False))
-                    self._centers_of = tree
-                device_route = tree
-            if device_route is not None:
-                Xc = np.ascontiguousarray(new_X, dtype=np.float64)
-                changed, block_of = self._ctx.assign_blocks(Xc)
-                if changed:
-                    self._block_of = block_of
-                    self._block_idxs = None
-                    self._blocks_pushed = "assignment"
-                self._jitter = None
-                self._ctx.set_unit_jitter(None)
+            if self._device_router() is not None:
+                self._push_blocks()              # (a partition given by the host is installed first: nothing is lost)
+                self._reblock_pending = True
             else:
                 self.block_idxs = self.block_fn(new_X)
                 self._push_blocks()
@@ -224,7 +234,15 @@ class GPRF(object):
         self._push_neighbors(neighbors)
 
         X = np.ascontiguousarray(self.X, dtype=np.float64)
-        rc, ll, gX, gC, bad = self._ctx.eval(X, grad_X, grad_cov)
+        if self._reblock_pending:
+            # update_X's re-blocking and the evaluation in one library call
+            rc, ll, gX, gC, bad, reblocked = self._ctx.update_eval(X, grad_X, grad_cov)
+            self._reblock_pending = False
+            if reblocked:
+                self._block_of, self._block_idxs = None, None
+                self._blocks_pushed = "device"
+        else:
+            rc, ll, gX, gC, bad = self._ctx.eval(X, grad_X, grad_cov)
         if rc == _capi.GPRF_NOT_PD:
             rc, ll, gX, gC = self._retry_with_jitter(X, grad_X, grad_cov, bad)
 

@@ -19,6 +19,7 @@
  *     0  GPRF_OK
  *     1  GPRF_NOT_PD     some unit's kernel matrix is not positive definite (jitchol would retry;
  *                        gpy_linalg.py:77-97) — *first_bad_unit says which; outputs are undefined
+ *     2  GPRF_RETRY      (asynchronous form only, see gprf_eval_status)
  *    <0  a HIP / argument error; gprf_last_error() has the text
  * No callbacks, no global state; host pointers are borrowed for the duration of the call only.
  * One context is bound to one device and one stream; calls on one context must not overlap.
@@ -36,6 +37,7 @@ typedef struct gprf_ctx gprf_ctx;
 
 #define GPRF_OK 0
 #define GPRF_NOT_PD 1
+#define GPRF_RETRY 2      /* gprf_eval_status only: a re-partition outgrew the workspace; it has been grown — enqueue again */
 #define GPRF_ERR_ARG (-1)
 #define GPRF_ERR_HIP (-2)
 #define GPRF_ERR_STATE (-3)
@@ -65,7 +67,10 @@ int gprf_set_theta(gprf_ctx *ctx, const double *theta, int32_t ntheta);
 
 /* self.block_idxs (gprf.py:100,172): CSR form of the list of index arrays; block b owns
  * point_idx[block_ptr[b] .. block_ptr[b+1]).  Order inside a block is kept (it fixes the row order of
- * the unit matrices, gprf.py:301,317-326).  Blocks may be empty (gprf.py:507-513). */
+ * the unit matrices, gprf.py:301,317-326).  Blocks may be empty (gprf.py:507-513) and points may be left out
+ * (their gradient rows are zero), but blocks must be DISJOINT: a point listed twice is refused with
+ * GPRF_ERR_ARG (every partition the reference's callers produce — Blocker.block_clusters, pdtree reblock — is
+ * one; the gradient scatter of gprf.py:258-273 is evaluated as a per-point gather here). */
 int gprf_set_blocks(gprf_ctx *ctx, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx);
 
 /* Fast host path for the reference's grid Blocker (block_clustering.py:17-26, called from update_X on EVERY
@@ -82,10 +87,13 @@ int gprf_set_block_assignment(gprf_ctx *ctx, int32_t n_blocks, const int32_t *bl
  * (n_centers x dx, row-major) in the context.  gprf_assign_blocks uploads X (n x dx), assigns every point to its
  * nearest centre ON THE DEVICE with exactly the arithmetic and tie rule of gprf_nearest_center, and compares
  * with the partition the unit tables were built from: *changed = 0 -> nothing else happens (the common case
- * between L-BFGS iterates); *changed = 1 -> the new partition is installed as by gprf_set_block_assignment
- * (n_blocks = n_centers) and, if block_of_out != NULL, copied there (n int32). */
+ * between L-BFGS iterates); *changed = 1 -> the unit tables (sizes, offsets, unit row -> point, point -> rows)
+ * have been rebuilt ON THE DEVICE for the new partition (points keep ascending index order inside a block, as
+ * gprf_set_block_assignment would give) and, if block_of_out != NULL, the partition is copied there (n int32).
+ * gprf_get_block_assignment copies the current partition (whoever made it) at any time. */
 int gprf_set_centers(gprf_ctx *ctx, int32_t n_centers, const double *centers);
 int gprf_assign_blocks(gprf_ctx *ctx, const double *X, int32_t *changed, int32_t *block_of_out);
+int gprf_get_block_assignment(gprf_ctx *ctx, int32_t *block_of_out);
 
 /* The same for the seismic driver's partition (run_seismic.py:375 passes pdtree_cluster's reblock as
  * block_fn, pdtree_clustering.py:65-94): a binary split tree of n_nodes nodes, node 0 the root, children with larger
@@ -125,6 +133,15 @@ int gprf_set_unit_jitter(gprf_ctx *ctx, int32_t n_units, const double *jitter);
 int gprf_eval(gprf_ctx *ctx, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
               double *gradX_out, double *gradC_out, int32_t *first_bad_unit);
 
+/* update_X + llgrad in ONE call — what the reference's objective callbacks do per L-BFGS-B function evaluation
+ * (gprfopt.py:377-417: gprf.update_X(xx) re-runs block_fn, gprf.py:169-174; then gprf.llgrad, gprf.py:206-296).
+ * Needs gprf_set_centers / gprf_set_split_tree.  X goes up once; the points are re-partitioned on the device;
+ * if any point changed block the unit tables are rebuilt there; the evaluation follows on the same stream; the
+ * result comes down; ONE synchronisation.  *reblocked (may be NULL) = 1 when the partition changed.  Other
+ * arguments and return values as gprf_eval. */
+int gprf_update_eval(gprf_ctx *ctx, const double *X, int32_t want_gradX, int32_t want_gradC, double *ll_out,
+                     double *gradX_out, double *gradC_out, int32_t *first_bad_unit, int32_t *reblocked);
+
 /* Same evaluation with device-resident input and output (the timed form; also what a multi-GPU caller
  * all-reduces).  d_X: n*dx doubles in HBM.  d_out: 1 + n*dx + ntheta doubles in HBM laid out
  * [ll | gradX row-major | gradC]; gradX / gradC parts are zero-filled when not requested.
@@ -132,7 +149,14 @@ int gprf_eval(gprf_ctx *ctx, const double *X, int32_t want_gradX, int32_t want_g
  * Follow with gprf_eval_status() after synchronising the stream. */
 int gprf_eval_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX, int32_t want_gradC,
                      double *d_out, void *stream);
-/* Blocks until the context's last evaluation has finished; returns GPRF_OK / GPRF_NOT_PD as gprf_eval. */
+/* gprf_update_eval's device-resident form: re-partition + (if needed) table rebuild + evaluation, all enqueued. */
+int gprf_update_eval_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX, int32_t want_gradC,
+                            double *d_out, void *stream);
+/* Blocks until the context's last evaluation has finished; returns GPRF_OK / GPRF_NOT_PD as gprf_eval, or
+ * GPRF_RETRY after a gprf_update_eval_device whose new partition did not fit the workspace (a unit grew past the
+ * launch-wide tile bound, or the matrices past the pools): d_out is undefined, the workspace has been grown and the
+ * new partition is installed — enqueue the evaluation again with gprf_eval_device.  (The host forms gprf_eval /
+ * gprf_update_eval do that themselves.) */
 int gprf_eval_status(gprf_ctx *ctx, int32_t *first_bad_unit);
 
 /* Bookkeeping a caller may want. */
@@ -140,6 +164,9 @@ int gprf_num_units(const gprf_ctx *ctx, int32_t *n_units_total, int32_t *n_units
 /* sum over local units of the algorithmic work of SURVEY.md §8d: flops = m^3 + 4 m^2 dy,
  * fill bytes = 8 m^2. */
 int gprf_work_estimate(gprf_ctx *ctx, double *flops, double *fill_bytes);
+/* How many times the unit tables have been (re)built on the device since the context was created (tests: an
+ * evaluation whose re-partition moved nobody must not rebuild). */
+int gprf_table_builds(gprf_ctx *ctx, int32_t *builds);
 
 /* HIP-event timing of the kernels, recorded on the stream the evaluation is enqueued on.
  * Stages: "gather","fill","potrf","solve","at","grad","assemble".  gprf_set_timing(ctx, 1) turns recording
@@ -159,7 +186,8 @@ int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
  * 4 per-row gradient slab (mp x 4), 5 [ll_u, logdet_u, zz_u, info_u], 6 eight in-kernel cycle
  * counters of diagnostic builds, 7 / 8 the gradient reduction's per-block column / row partials
  * (mp x TBm x 4, TBm = ceil(max local unit rows / 64)), 9 the unit's own (unweighted) gradient with respect to
- * theta (ntheta doubles; needs an evaluation run with want_gradC).  mp = m rounded up to 16.
+ * theta (ntheta doubles; needs an evaluation run with want_gradC), 10 the unit row -> point table of the unit (mp
+ * values, -1 in the padding).  mp = m rounded up to 16.
  * `stop_after` for gprf_debug_run: run the pipeline only up to a stage (0 = fill only ... 6 = all). */
 int gprf_debug_run(gprf_ctx *ctx, const double *X, int32_t stop_after);
 int gprf_debug_fetch(gprf_ctx *ctx, int32_t local_unit, int32_t what, double *out, int64_t out_len);

@@ -223,8 +223,9 @@ def test_update_X_fast_reblocking_path_equals_callable_path():
     X2[:3] = b.block_centers[:3]                     # points exactly on centres
     fast.update_X(X2)
     slow.update_X(X2)
-    assert fast._blocks_pushed == "assignment" and fast._block_idxs is None
+    assert fast._reblock_pending                     # nothing has happened yet: the re-blocking rides on the evaluation
     a, c = fast.llgrad(grad_X=True, grad_cov=True), slow.llgrad(grad_X=True, grad_cov=True)
+    assert fast._blocks_pushed == "device" and fast._block_idxs is None and not fast._reblock_pending
     assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
     assert all(np.array_equal(u, v) for u, v in zip(fast.block_idxs, slow.block_idxs))
     fast.close(); slow.close()
@@ -249,7 +250,8 @@ def test_device_reblocking_matches_host_and_oracle():
     g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01, neighbors=b.neighbors())
     g._ctx.set_centers(b.block_centers)
     changed, dev = g._ctx.assign_blocks(X)
-    assert changed                                    # first call installs
+    assert not changed and dev is None                # the constructor's (host) partition of X is this very one
+    dev = g._ctx.get_block_assignment()
     host = _capi.nearest_center(X, b.block_centers)
     ref = np.empty(n, dtype=np.int64)
     for i, idx in enumerate(bref.block_clusters(X)):
@@ -425,3 +427,107 @@ def test_generated_and_filled_kernel_matrices_give_the_same_evaluation(monkeypat
         g.close()
     assert np.isclose(out["1"][0], out["0"][0], rtol=1e-14)
     assert _close(out["1"][1], out["0"][1], 1e-12) and np.allclose(out["1"][2], out["0"][2], rtol=1e-11)
+
+
+def _unit_tables(g):
+    ctx = g._ctx
+    return [ctx.debug_fetch(l, 10) for l in range(ctx.num_units()[1])]
+
+
+def test_device_built_unit_tables_equal_host_partition_tables():
+    """after update_X the unit tables (sizes, offsets, unit row -> point, a point's rows) are built on the
+    device from the device's own partition (k_assign -> k_unit_scan -> k_place).  They must be the tables an uploaded
+    host partition gives (gprf_set_blocks with Blocker.block_clusters' lists): identical row -> point tables, bit-
+    identical (ll, gradX, gradC) on every iterate of a walk that re-partitions each time; an iterate that moves nobody
+    across a border rebuilds nothing; block_idxs read back equals the host Blocker's."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(33)
+    n = 5000
+    X = rng.rand(n, 2)
+    Y = rng.randn(n, 7)
+    b = Blocker(grid_centers(36))
+    cov = GPCov([1.0], [0.1, 0.1], "euclidean", "se")
+    fast = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=b.neighbors())
+    slow = GPRF(X, Y, lambda Z: b.block_clusters(Z), cov, 0.01, neighbors=b.neighbors())
+    Xk = X
+    for k in range(5):
+        Xk = Xk + 0.01 * rng.randn(n, 2)
+        fast.update_X(Xk); slow.update_X(Xk)
+        a, c = fast.llgrad(grad_X=True, grad_cov=True), slow.llgrad(grad_X=True, grad_cov=True)
+        assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2]), k
+        ta, tc = _unit_tables(fast), _unit_tables(slow)
+        assert len(ta) == len(tc) and all(np.array_equal(u, v) for u, v in zip(ta, tc)), k
+    assert fast._block_idxs is None                    # nothing came back to the host in between
+    builds = fast._ctx.table_builds()
+    fast.update_X(Xk + 1e-9)                           # nobody crosses a border
+    again = fast.llgrad(grad_X=True, grad_cov=True)
+    assert fast._ctx.table_builds() == builds          # ... so the tables were not rebuilt
+    slow.update_X(Xk + 1e-9)
+    c = slow.llgrad(grad_X=True, grad_cov=True)
+    assert again[0] == c[0] and np.array_equal(again[1], c[1])
+    assert all(np.array_equal(u, v) for u, v in zip(fast.block_idxs, b.block_clusters(Xk + 1e-9)))
+    fast.close(); slow.close()
+
+
+def test_reblocking_that_outgrows_the_workspace_is_repeated():
+    """A re-partition that makes a unit larger than anything the launch was sized for (more tiles per edge, bigger
+    matrix pools) is detected on the device (k_unit_scan), the workspace grows and the evaluation is repeated inside
+    the same gprf_update_eval call: same numbers as a fresh context on the new partition."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(34)
+    n = 1800
+    X = rng.rand(n, 2)
+    Y = rng.randn(n, 4)
+    b = Blocker(grid_centers(16))
+    cov = GPCov([1.0], [0.15, 0.15], "euclidean", "se")
+    g = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=b.neighbors())
+    g.llgrad(grad_X=True)
+    big0 = max(len(v) for v in g.block_idxs)
+    X2 = X.copy()
+    movers = rng.choice(n, 500, replace=False)
+    X2[movers] = b.block_centers[5] + 0.01 * rng.randn(500, 2)          # 500 points pile into block 5
+    g.update_X(X2)
+    a = g.llgrad(grad_X=True, grad_cov=True)
+    assert max(len(v) for v in g.block_idxs) > big0 + 300
+    fresh = GPRF(X2, Y, None, cov, 0.01, block_idxs=b.block_clusters(X2), neighbors=b.neighbors())
+    c = fresh.llgrad(grad_X=True, grad_cov=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+    # and back again: THIS evaluation still runs under the large launch bound (other kernel instantiations than a fresh
+    # context picks: equal to rounding, not to the bit); the bound has followed by the next one
+    g.update_X(X)
+    a = g.llgrad(grad_X=True)
+    fresh.close()
+    fresh = GPRF(X, Y, None, cov, 0.01, block_idxs=b.block_clusters(X), neighbors=b.neighbors())
+    c = fresh.llgrad(grad_X=True)
+    assert np.isclose(a[0], c[0], rtol=1e-13) and _close(a[1], c[1], 1e-12)
+    g.update_X(X + 1e-12)
+    a = g.llgrad(grad_X=True)
+    fresh.update_X(X + 1e-12)
+    c = fresh.llgrad(grad_X=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1])
+    g.close(); fresh.close()
+
+
+def test_set_blocks_refuses_a_point_listed_twice():
+    """blocks must be disjoint (include/gprf_hip.h); a duplicate is an argument error, not a silent wrong
+    gradient.  Points left out of every block are allowed and get a zero gradient row."""
+    from gprf_amd import GPCov, _capi
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(35)
+    X, Y = rng.rand(60, 2), rng.randn(60, 3)
+    cov = GPCov([1.0], [0.3, 0.3], "euclidean", "se")
+    blocks = [np.arange(0, 30), np.arange(29, 60)]                       # point 29 twice
+    with pytest.raises(_capi.GprfHipError, match="listed twice"):
+        GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=[(1, 0)])
+    blocks = [np.arange(0, 25), np.arange(30, 60)]                       # points 25..29 in no block
+    g = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=[(1, 0)])
+    ll, gX, _ = g.llgrad(grad_X=True)
+    assert np.all(gX[25:30] == 0.0) and np.all(np.any(gX[:25] != 0.0, axis=1))
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    r = GPRFRef(X, Y, None, OC([1.0], [0.3, 0.3], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=[(1, 0)])
+    o = r.llgrad(grad_X=True)
+    assert np.isclose(ll, o[0], rtol=1e-12) and _close(gX, o[1], 1e-10)
+    g.close()
