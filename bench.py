@@ -6,22 +6,25 @@ Workload: n=10000, 100 grid blocks, yd=50, lscale=0.06, obs_std=0.02, noise 0.01
 GPRF objective: 100 unary units + 342 neighbouring block-pair units), task x (gradient w.r.t. X), synthetic
 inputs regenerated from seed 0 by the reference's recipe (gprf_amd/synthetic.py).
 
-One "step" = one objective+gradient evaluation of every unit: gather -> K fill -> Cholesky -> triangular
-solves -> gradient reduce -> Bethe-weighted assembly (+ one all-reduce when N > 1), with X, Y, hypers and the
-unit tables already resident in HBM and the result left in HBM (gprf_eval_device).  Steps cycle over 10
-distinct X (the first L-BFGS-B iterates, each with its own re-blocking), enqueued back to back on one
-stream.  N > 1 ("strong" scaling): the SAME evaluation's units are sharded over the ranks (LPT on
-m^3 + 4 m^2 dy) and each step ends with a single RCCL all-reduce of 1 + n*dx + ncov doubles.
+One "step" = ONE objective+gradient evaluation exactly as the reference's L-BFGS-B callback issues it
+(gprfopt.py:377-417): host X in -> GPRF.update_X(X) (re-runs the block function: re-partition, here on
+the device) -> GPRF.llgrad(grad_X=True) -> host (ll, gradX) out, the evaluation completely finished — result on the
+host, all-reduce included when N > 1 — before the next one starts.  Steps cycle over 10 distinct X (the first
+L-BFGS-B iterates: every step re-partitions).  `value` = steps / wall time of that sequential loop.
+N > 1 ("strong" scaling): the SAME evaluation's units are sharded over the ranks (LPT on m^3 + 4 m^2 dy); every rank
+holds X, Y, theta; each evaluation ends with a single RCCL all-reduce of 1 + n*dx + ncov (+2 status) doubles.
 
-Rank 0 prints ONE JSON line.  Extra keys: "roofline" (dominant kernel, HIP-event timed inside the timed
-region), "cpu_baseline" (the oracle's reference-shaped CPU port on this box's host cores), "stages_ms",
-"sync_evals_per_s" (one host sync + D2H per evaluation, as an optimiser would call it),
-"host_inclusive_evals_per_s" (Python update_X incl. host re-blocking + llgrad with H2D/D2H), and
-"local_gp_evals_per_s" (BASELINE configs[1], no pairs).
+Rank 0 prints ONE JSON line.  Extra keys: "roofline" (dominant kernel, HIP-event timed inside the timed region),
+"cpu_baseline" (the oracle's CPU port on this box's host cores), "stages_ms", "device_resident_evals_per_s" (the
+same evaluations enqueued back to back with X / result left in HBM and no host synchronisation: the kernels' own
+rate), "llgrad_only_evals_per_s" (blocks fixed, no update_X), "local_gp_evals_per_s" (BASELINE configs[1], no pairs)
+and "c4_evals_per_s" (BASELINE configs[3]: n=80000, 841 blocks + 3192 pairs, task xcov — the configuration whose
+work is large enough to shard), measured the same sequential way at every N.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +37,7 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak (vendor data sheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): clock under load
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def parse():
@@ -50,12 +54,13 @@ def parse():
     ap.add_argument("--task", default="x", choices=["x", "xcov"])
     ap.add_argument("--distinct-x", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the BASELINE configs[3] leg (n=80000)")
     ap.add_argument("--only-north-star", action="store_true",
-                    help="profiling runs: skip the secondary legs (fill-rate, synchronous, host-inclusive, local-GP, CPU) "
-                         "so that every kernel launch of the process has the north-star shapes")
+                    help="profiling runs: skip the secondary legs so that every kernel launch of the process has the "
+                         "north-star shapes")
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="diagnostic: no HIP events between the kernels in the timed region (no roofline then)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     return ap.parse_args()
 
 
@@ -72,36 +77,123 @@ def algorithmic_flops(sizes, dy):
     }
 
 
-def cpu_baseline(sd, local_dist, seconds, grad_cov):
-    """The oracle (CPU port of the reference path) timed on this box's host cores.  (A) reference-shaped:
-    serial Python loop over units, one Python->C call per (point, coordinate) for the kernel derivative rows
-    (gprf.py:556-561), LAPACK dpotrf+dtrtri+dpotri+dpotrs as pdinv/dpotrs do; BLAS threads = all cores.
-    (B) the same arithmetic with the per-row calls hoisted into C."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+_POOL_STATE = {}
+
+
+def _pool_init(X, Y, lscale, nv, blocks, nbrs):
+    from threadpoolctl import threadpool_limits
+    _POOL_STATE["limit"] = threadpool_limits(limits=1)      # (kept alive; the environment variables set by the parent
+                                                            # already start the BLAS of a spawned worker single-threaded)
     from oracle.gprf_ref import GPRFRef
     from oracle.vector_tree import GPCov
+    _POOL_STATE["g"] = GPRFRef(X, Y, None, GPCov([1.0], [lscale, lscale], "euclidean", "se"), nv, block_idxs=blocks,
+                               neighbors=nbrs, mode="matrix")
+
+
+def _pool_unit(u):
+    g = _POOL_STATE["g"]
+    nb = g.n_blocks
+    if u < nb:
+        r = g.llgrad_unary(u, grad_X=True)
+    else:
+        i, j = g.neighbors[u - nb]
+        r = g.llgrad_joint(i, j, grad_X=True)
+    return float(r[0])
+
+
+def cpu_baseline(sd, local_dist, seconds, grad_cov):
+    """The oracle (CPU port of the reference path, kind "port") timed on this box's host cores, on a bounded sample.
+
+    (A) reference-shaped: serial loop over units, one Python->C call per (point, coordinate) for the kernel derivative
+        rows (gprf.py:556-561), LAPACK dpotrf+dtrtri+dpotri+dpotrs as pdinv/dpotrs do (oracle mode="rows"); BLAS
+        threads = 1 and = all cores.  Sample: every 6th unit of the size-sorted unit list (an unbiased estimate of the sum
+        over units), each timed 3 times (median), extrapolated to all units; `value` = the faster of the two.
+    (B) best-effort CPU: the same arithmetic with the per-row calls hoisted into C (mode="matrix"), ALL units fanned
+        over a process pool (one BLAS thread per worker), 3 full evaluations (median)."""
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov
+    from threadpoolctl import threadpool_limits
+    cores = os.cpu_count() or 1
+    nbrs = sd.neighbors if local_dist < 1.0 else []
+    g = GPRFRef(sd.X_obs, sd.SY, sd.reblock, GPCov([1.0], [sd.lscale, sd.lscale], "euclidean", "se"), sd.noise_var,
+                block_idxs=sd.block_idxs, neighbors=nbrs, mode="rows")
+    nb, nu = g.n_blocks, g.n_blocks + len(nbrs)
+    sizes = [len(b) for b in sd.block_idxs] + [len(sd.block_idxs[i]) + len(sd.block_idxs[j]) for (i, j) in nbrs]
+    order = np.argsort(sizes, kind="stable")
+    stride = 6
+    sample = order[stride // 2::stride]
+
+    def unit(u):
+        if u < nb:
+            return g.llgrad_unary(u, grad_X=True, grad_cov=grad_cov)
+        i, j = nbrs[u - nb]
+        return g.llgrad_joint(i, j, grad_X=True, grad_cov=grad_cov)
+
+    t_blocking = []
+    for _ in range(3):                          # update_X's host re-blocking (gprf.py:171-172), part of one evaluation
+        t0 = time.perf_counter()
+        g.update_X(sd.X_obs)
+        t_blocking.append(time.perf_counter() - t0)
+    rows = {}
+    for threads in (1, cores):
+        with threadpool_limits(limits=threads):
+            times = dict((int(u), []) for u in sample)
+            t_end = time.perf_counter() + 0.4 * seconds
+            for rep in range(3):                # whole passes over the sample; at least one, three if the budget allows
+                for u in times:
+                    t0 = time.perf_counter()
+                    unit(u)
+                    times[u].append(time.perf_counter() - t0)
+                if time.perf_counter() > t_end:
+                    break
+        tot = sum(float(np.median(v)) for v in times.values())
+        est = tot * (nu / float(len(sample))) + float(np.median(t_blocking))
+        rows[threads] = (1.0 / est, min(len(v) for v in times.values()))
+    best_threads = max(rows, key=lambda t: rows[t][0])
+    out = {"value": rows[best_threads][0], "unit": "evals/s", "cores": best_threads, "kind": "port",
+           "sample": "oracle mode=rows (reference-shaped: per-(point,coordinate) derivative calls, dpotrf+dtrtri+dpotri+dpotrs): "
+                     "every %dth unit of the %d (size-sorted; %d units), each timed up to 3x (median; >= %d x), extrapolated "
+                     "x%.2f + update_X re-blocking (median of 3); BLAS threads %d (faster of 1 / %d)"
+                     % (stride, nu, len(sample), min(r[1] for r in rows.values()), nu / float(len(sample)), best_threads, cores),
+           "rows_blas1_evals_per_s": rows[1][0], "rows_blas_all_evals_per_s": rows[cores][0], "host_cores": cores}
+    # (B) process pool over ALL units, vectorised per-unit arithmetic
+    saved = {}
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        import multiprocessing as mp
+        nproc = min(cores, 64)
+        ctx = mp.get_context("spawn")      # (never fork a process that has initialised the GPU)
+        saved = dict((k, os.environ.get(k)) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"))
+        for k in saved:
+            os.environ[k] = "1"
+        with ctx.Pool(nproc, initializer=_pool_init,
+                      initargs=(sd.X_obs, sd.SY, sd.lscale, sd.noise_var, sd.block_idxs, nbrs)) as pool:
+            # (bounded: a pool that crawls — oversubscribed BLAS threads on a big host — must not eat the bench's minutes)
+            pool.map_async(_pool_unit, range(nu), chunksize=max(1, nu // (4 * nproc))).get(timeout=90)      # warm-up
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pool.map_async(_pool_unit, [int(u) for u in order[::-1]], chunksize=1).get(timeout=30)      # largest first
+                ts.append(time.perf_counter() - t0 + float(np.median(t_blocking)))
+        out["pool_value"] = 1.0 / float(np.median(ts))
+        out["pool_sample"] = "oracle mode=matrix, all %d units over a %d-process pool (1 BLAS thread each), 3 full evaluations (median)" % (nu, nproc)
+    except Exception as e:      # the pool is a side figure: never lose the bench line over it
+        out["pool_value"] = None
+        out["pool_sample"] = "process pool failed: %r" % (e,)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
-        threads = os.cpu_count() or 1
-    out = {}
-    for mode in ("rows", "matrix"):
-        g = GPRFRef(sd.X_obs, sd.SY, sd.reblock, GPCov([1.0], [sd.lscale, sd.lscale], "euclidean", "se"),
-                    sd.noise_var, block_idxs=sd.block_idxs, neighbors=sd.neighbors if local_dist < 1.0 else [],
-                    mode=mode)
-        n_done, t0 = 0, time.time()
-        while True:
-            g.update_X(sd.X_obs)
-            g.llgrad(grad_X=True, grad_cov=grad_cov)
-            n_done += 1
-            if time.time() - t0 > seconds / 2:
-                break
-        out[mode] = (n_done / (time.time() - t0), n_done)
-    return {"value": out["rows"][0], "unit": "evals/s", "cores": threads, "kind": "port",
-            "sample": "%d full evaluation(s) of the same workload (all %d units), oracle mode=rows "
-                      "(reference-shaped per-row derivative calls), BLAS threads=%d" % (out["rows"][1], g.n_blocks + len(g.neighbors), threads),
-            "vectorised_value": out["matrix"][0],
-            "vectorised_sample": "%d full evaluation(s), oracle mode=matrix" % out["matrix"][1]}
+        return None
 
 
 TIMING_PERIOD = 7
@@ -139,26 +231,60 @@ def main():
 
     from gprf_amd import grid_centers, _capi
     from gprf_amd import dist as gdist
+    from gprf_amd.gprf import GPRF
     from gprf_amd.objective import Objective
     from gprf_amd.synthetic import SampledData
 
-    # ---------------- inputs (reference recipe, seed 0); rank 0 samples, everyone gets the same bytes
-    ntrain, ntest = args.ntrain, 500
-    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gprf_bench_data")
-    if rank == 0:
-        sd = SampledData(n=ntrain + ntest, ntrain=ntrain, lscale=args.lscale, obs_std=args.obs_std, yd=args.yd,
-                         seed=0, use_gpu=True, cache_dir=cache)
-    if world > 1:
-        dist.barrier()
-        if rank != 0:
-            sd = SampledData(n=ntrain + ntest, ntrain=ntrain, lscale=args.lscale, obs_std=args.obs_std, yd=args.yd,
-                             seed=0, use_gpu=True, cache_dir=cache)
-        ySY = torch.as_tensor(sd.SY, device=dev)
-        dist.broadcast(ySY, 0)
-        sd.SY = np.ascontiguousarray(ySY.cpu().numpy())
-    sd.set_centers(grid_centers(args.nblocks))
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def sample(ntrain, lscale, obs_std, nblocks):
+        """reference recipe, seed 0; rank 0 samples (N x N prior Cholesky on its GPU), everyone gets the same bytes"""
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gprf_bench_data")
+        kw = dict(n=ntrain + 500, ntrain=ntrain, lscale=lscale, obs_std=obs_std, yd=args.yd, seed=0, use_gpu=True, cache_dir=cache)
+        sd = SampledData(**kw) if rank == 0 else None
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                sd = SampledData(**kw)      # (cached by rank 0 when TMPDIR is shared; the broadcast below decides)
+            ySY = torch.as_tensor(sd.SY, device=dev)
+            dist.broadcast(ySY, 0)
+            sd.SY = np.ascontiguousarray(ySY.cpu().numpy())
+        sd.set_centers(grid_centers(nblocks))
+        return sd
+
+    def sequential_rate(g, Xlist, steps, warmup, grad_cov, timing_period=0):
+        """THE metric's loop: update_X + llgrad, one evaluation finished before the next starts; -> (evals/s, ms)"""
+        nXl = len(Xlist)
+        for k in range(warmup):
+            g.update_X(Xlist[k % nXl])
+            g.llgrad(grad_X=True, grad_cov=grad_cov)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            sampled = timing_period and k % timing_period == 0
+            if sampled:
+                g._ctx.set_timing(True)
+            g.update_X(Xlist[k % nXl])
+            g.llgrad(grad_X=True, grad_cov=grad_cov)
+            if sampled:
+                g._ctx.set_timing(False)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return steps / el, 1e3 * el / steps
+
+    # ---------------- inputs
+    ntrain = args.ntrain
+    sd = sample(ntrain, args.lscale, args.obs_std, args.nblocks)
     grad_cov = args.task == "xcov"
     n, dx = sd.X_obs.shape
+    nbrs = sd.neighbors if args.local_dist < 1.0 else []
 
     # ---------------- 10 distinct X: the first L-BFGS-B iterates (rank 0, unsharded), then broadcast
     nX = args.distinct_x
@@ -189,91 +315,37 @@ def main():
         t = torch.as_tensor(Xs, device=dev)
         dist.broadcast(t, 0)
         Xs = t.cpu().numpy()
+    Xlist = [np.ascontiguousarray(Xs[k]) for k in range(nX)]
+    sizes_all = [gdist.unit_sizes(sd.reblock(Xs[k]), nbrs) for k in range(nX)]
 
-    # ---------------- one sharded context per distinct X (its own blocks, tables and workspace in HBM)
-    evs, sizes_all = [], []
-    for k in range(nX):
-        blocks = sd.reblock(Xs[k])
-        nbrs = sd.neighbors if args.local_dist < 1.0 else []
-        from gprf_amd.gprf import GPRF
-        g = GPRF(Xs[k], sd.SY, None, sd.cov, sd.noise_var, block_idxs=blocks, neighbors=nbrs, device=local_rank,
-                 shard=(rank, world))
-        g._push_neighbors(nbrs)
-        ev = gdist.DeviceEvaluator(g)
-        ev.set_X(Xs[k])
-        evs.append(ev)
-        sizes_all.append(gdist.unit_sizes(blocks, nbrs))
-    torch.cuda.synchronize()
-    # every evaluation of the timed region goes on ONE stream, strictly one after the other, as an
-    # optimiser would issue them (no overlap between consecutive evaluations)
-    run_stream = torch.cuda.Stream(device=dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---------------- warmup, then EXACTLY --steps timed steps
-    for k in range(args.warmup):
-        evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
-    barrier()
-    # HIP events between the kernels cost ~3 us of stream time each (25 us per evaluation with all 8 of them):
-    # the stage durations are sampled on every TIMING_PERIOD-th evaluation of the timed region (a period coprime
-    # with the number of distinct X, so every context is sampled)
-    for ev in evs:
-        ev.g._ctx.set_timing(True, reset=True)
-        ev.g._ctx.set_timing(False)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        e = evs[k % nX]
-        sampled = (not args.no_stage_timing) and k % TIMING_PERIOD == 0
-        if sampled:
-            e.g._ctx.set_timing(True)
-        e.enqueue(True, grad_cov, stream=run_stream)
-        if sampled:
-            e.g._ctx.set_timing(False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for ev in evs:
-        rc, bad = ev.g._ctx.eval_status()
-        assert rc == _capi.GPRF_OK, "unit %d not positive definite" % bad
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    # ---------------- the timed region: the reference's GPRF object, sharded over the ranks
+    g = sd.build_gprf(local_dist=args.local_dist, device=local_rank, shard=(rank, world))
+    g._ctx.set_timing(True, reset=True)
+    g._ctx.set_timing(False)
+    value, ms_per_step = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov,
+                                         0 if args.no_stage_timing else TIMING_PERIOD)
     if args.no_stage_timing:
         if rank == 0:
-            print(json.dumps({"diagnostic": "no HIP events between kernels in the timed region", "value": args.steps / elapsed,
-                              "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps, "n_gpus": world}))
+            print(json.dumps({"diagnostic": "no HIP events between kernels in the timed region", "value": value,
+                              "unit": "evals/s", "ms_per_step": ms_per_step, "n_gpus": world}))
+        g.close()
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
         return
     # per-stage averages over the timed region (HIP events on the launch stream), this rank's shard
-    used = [ev for i, ev in enumerate(evs) if i < args.steps]
-    stage = {}
-    cnt = 0
-    for ev in used:
-        try:
-            tm = ev.g._ctx.get_timing()
-        except _capi.GprfHipError:      # a context the sampling never reached (very short runs)
-            continue
-        c = tm.pop("count")
-        cnt += c
-        for kname, v in tm.items():
-            stage[kname] = stage.get(kname, 0.0) + v * c
-    stage = {kname: v / max(cnt, 1) for kname, v in stage.items()}
-    for ev in evs:
-        ev.g._ctx.set_timing(False)
+    tm = g._ctx.get_timing()
+    cnt = tm.pop("count")
+    stage = dict(tm)
 
-    value = args.steps / elapsed
     result = None
     if rank == 0:
         # algorithmic work of this rank's shard, averaged over the distinct X
         fl = {}
         for k in range(nX):
             owner = _capi.partition_units(sizes_all[k], args.yd, world)
-            f = algorithmic_flops(sizes_all[k][owner == 0], args.yd)
-            for a, b in f.items():
+            f_ = algorithmic_flops(sizes_all[k][owner == 0], args.yd)
+            for a, b in f_.items():
                 fl[a] = fl.get(a, 0.0) + b / nX
         total_all = float(np.mean([algorithmic_flops(s, args.yd)["total"] for s in sizes_all]))
         compute_stages = ["potrf", "solve", "at", "grad"]
@@ -289,89 +361,119 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01f_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             key = {"potrf": "k_potrf_reg_gen", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 roof["traffic"] = tr[key]["bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01f_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), profiled at commit %s; this run: %s" % (
+                    TRAFFIC_FILE, tr.get("commit", "?"), git_head())
         except Exception:
             pass
         roof["avg_launch_ms"] = stage[dom]
         roof["algorithmic_per_launch"] = fl["fill_bytes"] if dom == "fill" else fl[dom]
-        if world == 1 and not args.only_north_star:
-            # K is generated inside k_potrf_reg on this configuration and k_fill does not run; the fill kernel's
-            # HBM write rate is measured on the side by forcing the K pool back for a few evaluations
-            os.environ["GPRF_FUSED_FILL"] = "0"
-            e = evs[0]
-            e.g._ctx.set_timing(True, reset=True)
-            for _ in range(8):
-                e.enqueue(True, grad_cov, stream=run_stream)
-            torch.cuda.synchronize()
-            tmf = e.g._ctx.get_timing()
-            e.g._ctx.set_timing(False, reset=True)
-            del os.environ["GPRF_FUSED_FILL"]
-            roof["fill_kernel"] = {"GBps": fl["fill_bytes"] / (tmf["fill"] * 1e-3) / 1e9, "ms": tmf["fill"],
-                                   "potrf_ms_reading_K": tmf["potrf"],
-                                   "note": "k_fill timed with GPRF_FUSED_FILL=0; by default k_potrf_reg generates K "
-                                           "and it never exists in HBM (stages_ms.fill is then two event records)"}
         roof["mfma_f64_measured_peak"] = FP64_MFMA_MEASURED_TFLOPS
-        roof["whole_eval_TFLOPs"] = total_all * value / 1e12
-        roof["whole_eval_frac_of_fp64_peak"] = total_all * value / 1e12 / (FP64_PEAK_TFLOPS * world)
+        kernels_ms = sum(stage[s] for s in stage)
+        roof["whole_eval_TFLOPs_kernels"] = total_all / (kernels_ms * 1e-3) / 1e12 if world == 1 else None
+        roof["whole_eval_frac_of_fp64_peak_kernels"] = (total_all / (kernels_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if world == 1 else None
         result = {
             "metric": "GPRF objective+gradient evals/sec, n=%d nblocks=%d yd=%d" % (ntrain, args.nblocks, args.yd),
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "n=%d nblocks=%d yd=%d lscale=%g obs_std=%g local_dist=%g (%d unary + %d pair units) task=%s"
                                    % (ntrain, args.nblocks, args.yd, args.lscale, args.obs_std, args.local_dist,
-                                      args.nblocks, len(sd.neighbors) if args.local_dist < 1.0 else 0, args.task),
-                       "distinct_X": nX, "parallelism": "units sharded over %d rank(s), 1 all-reduce/eval" % world},
+                                      args.nblocks, len(nbrs), args.task),
+                       "distinct_X": nX,
+                       "step": "host X in -> update_X (device re-partition + table rebuild) -> llgrad -> host result out, "
+                               "sequential, one synchronisation per evaluation",
+                       "parallelism": "units sharded over %d rank(s), 1 all-reduce/eval" % world},
             "roofline": roof,
             **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks time-share one GPU over gloo; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
-            "stage_timing": "HIP events between the kernels on every %d-th evaluation of the timed region (%d sampled)"
-                            % (TIMING_PERIOD, cnt),
+            "kernels_ms_per_eval": round(kernels_ms, 5),
+            "stage_timing": "HIP events between the kernels on every %d-th evaluation of the timed region (%d sampled); "
+                            "'gather' includes the re-partition and table-build kernels" % (TIMING_PERIOD, cnt),
         }
 
-    # ---------------- secondary rates (N = 1 only): synchronous, host-inclusive, local-GP config
+    # ---------------- secondary figures
+    if not args.only_north_star:
+        # blocks fixed (no update_X): the llgrad-only rate of SURVEY 8d
+        g.update_X(Xlist[0])
+        g.llgrad(grad_X=True, grad_cov=grad_cov)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            g.llgrad(grad_X=True, grad_cov=grad_cov)
+        barrier()
+        if rank == 0:
+            result["llgrad_only_evals_per_s"] = 50.0 / (time.perf_counter() - t1)
     if world == 1 and not args.only_north_star:
-        ev = evs[0]
-        ts = []
-        for k in range(min(args.steps, 50)):
-            t1 = time.perf_counter()
+        # the kernels' own rate: the same evaluations enqueued back to back on one stream, X / result resident in HBM,
+        # no host synchronisation inside the loop (one context per distinct X, its tables built beforehand)
+        run_stream = torch.cuda.Stream(device=dev)
+        evs = []
+        for k in range(nX):
+            gk = GPRF(Xlist[k], sd.SY, None, sd.cov, sd.noise_var, block_idxs=sd.reblock(Xlist[k]), neighbors=nbrs,
+                      device=local_rank)
+            gk._push_neighbors(nbrs)
+            ev = gdist.DeviceEvaluator(gk)
+            ev.set_X(Xlist[k])
+            evs.append(ev)
+        for k in range(20):
             evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
-            evs[k % nX].result(True, grad_cov)
-            ts.append(time.perf_counter() - t1)
-        result["sync_evals_per_s"] = 1.0 / float(np.median(ts))
-        gh = sd.build_gprf(local_dist=args.local_dist, device=local_rank)
-        gh.llgrad(grad_X=True)
-        ts = []
-        for k in range(min(args.steps, 30)):
-            t1 = time.perf_counter()
-            gh.update_X(Xs[k % nX])
-            gh.llgrad(grad_X=True, grad_cov=grad_cov)
-            ts.append(time.perf_counter() - t1)
-        result["host_inclusive_evals_per_s"] = 1.0 / float(np.median(ts))
-        gh.close()
-        gl = sd.build_gprf(local_dist=1.0, device=local_rank)
-        el = gdist.DeviceEvaluator(gl)
-        gl._push_neighbors(gl.neighbors)
-        el.set_X(sd.X_obs)
-        for _ in range(10):
-            el.enqueue(True, grad_cov, stream=run_stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(100):
-            el.enqueue(True, grad_cov, stream=run_stream)
+        for k in range(args.steps):
+            evs[k % nX].enqueue(True, grad_cov, stream=run_stream)
         torch.cuda.synchronize()
-        result["local_gp_evals_per_s"] = 100.0 / (time.perf_counter() - t1)
+        result["device_resident_evals_per_s"] = args.steps / (time.perf_counter() - t1)
+        # K is generated inside k_potrf_reg on this configuration and k_fill does not run; the fill kernel's HBM
+        # write rate is measured on the side by forcing the K pool back for a few evaluations
+        os.environ["GPRF_FUSED_FILL"] = "0"
+        e = evs[0]
+        e.g._ctx.set_timing(True, reset=True)
+        for _ in range(8):
+            e.enqueue(True, grad_cov, stream=run_stream)
+        torch.cuda.synchronize()
+        tmf = e.g._ctx.get_timing()
+        e.g._ctx.set_timing(False, reset=True)
+        del os.environ["GPRF_FUSED_FILL"]
+        f0 = algorithmic_flops(sizes_all[0], args.yd)
+        result["roofline"]["fill_kernel"] = {
+            "GBps": f0["fill_bytes"] / (tmf["fill"] * 1e-3) / 1e9, "ms": tmf["fill"], "potrf_ms_reading_K": tmf["potrf"],
+            "note": "k_fill timed with GPRF_FUSED_FILL=0; by default k_potrf_reg generates K and it never exists in HBM "
+                    "(stages_ms.fill is then two event records)"}
+        for ev in evs:
+            ev.g.close()
+        # BASELINE configs[1]: no pairs
+        gl = sd.build_gprf(local_dist=1.0, device=local_rank)
+        result["local_gp_evals_per_s"] = sequential_rate(gl, Xlist, 100, 10, grad_cov)[0]
         gl.close()
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sd, args.local_dist, args.cpu_seconds, grad_cov)
-            result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
+    g.close()
 
-    for ev in evs:
-        ev.g.close()
+    # ---------------- BASELINE configs[3] (n=80000, 841 blocks + 3192 pairs, task xcov), same sequential loop, every N
+    if not args.only_north_star and not args.no_c4 and args.ntrain == 10000:
+        sd4 = sample(80000, 0.02, 0.002, 800)
+        g4 = sd4.build_gprf(local_dist=0.5, device=local_rank, shard=(rank, world))
+        rng = np.random.RandomState(1)
+        X4 = [np.ascontiguousarray(sd4.X_obs + 0.25 * sd4.obs_std * k * rng.randn(*sd4.X_obs.shape)) for k in range(3)]
+        c4, c4ms = sequential_rate(g4, X4, 30, 5, True)
+        if rank == 0:
+            s4 = gdist.unit_sizes(sd4.block_idxs, sd4.neighbors)
+            result["c4_evals_per_s"] = c4
+            result["c4"] = {"workload": "n=80000 nblocks=800(841) yd=50 lscale=0.02 obs_std=0.002 local_dist=0.5 (841 unary + %d pair "
+                                        "units) task=xcov, prior draw by dense fp64 Cholesky at N=80500 on the GPU" % len(sd4.neighbors),
+                            "ms_per_eval": c4ms, "steps": 30, "distinct_X": 3,
+                            "algorithmic_TFLOPs": algorithmic_flops(s4, 50)["total"] * c4 / 1e12}
+        g4.close()
+        del sd4
+
+    if world == 1 and not args.only_north_star and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, args.local_dist, args.cpu_seconds, grad_cov)
+        result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
+        if result["cpu_baseline"].get("pool_value"):
+            result["speedup_vs_cpu_pool"] = value / result["cpu_baseline"]["pool_value"]
+
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():

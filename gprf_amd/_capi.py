@@ -45,6 +45,7 @@ SIGNATURES = {
     "gprf_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "gprf_update_eval_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "gprf_eval_status": (ctypes.c_int, [_vp, _i32p]),
+    "gprf_last_reblocked": (ctypes.c_int, [_vp, _i32p]),
     "gprf_num_units": (ctypes.c_int, [_vp, _i32p, _i32p]),
     "gprf_work_estimate": (ctypes.c_int, [_vp, _dp, _dp]),
     "gprf_table_builds": (ctypes.c_int, [_vp, _i32p]),
@@ -282,6 +283,11 @@ class Context(object):
         bad = _i32(-1)
         rc = self._check(self.lib.gprf_eval_status(self.h, ctypes.byref(bad)), "gprf_eval_status")
         return rc, bad.value
+
+    def last_reblocked(self):
+        r = _i32(0)
+        self._check(self.lib.gprf_last_reblocked(self.h, ctypes.byref(r)), "gprf_last_reblocked")
+        return bool(r.value)
 
     def num_units(self):
         a, b = _i32(0), _i32(0)

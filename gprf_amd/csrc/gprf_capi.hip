@@ -135,6 +135,7 @@ struct gprf_ctx {
     double stage_ms_last[GPRF_N_STAGES] = {};
     bool eval_pending = false;
     bool pending_reblocked = false;       // the pending evaluation ran the partition kernel
+    bool last_reblocked = false;          // ... and the last finished one changed the partition
     hipStream_t last_stream = nullptr;    // stream of the last enqueue (gprf_eval_status synchronises it)
     hipEvent_t ev_tables = nullptr;       // recorded on the context stream after a table upload
     hipEvent_t ev_last = nullptr;         // recorded behind the last evaluation on whatever stream it went to
@@ -608,7 +609,10 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
     HIP_TRY(c, hipStreamSynchronize(s));
     c->eval_pending = false;
     if (first_bad_unit) *first_bad_unit = -1;
-    int rc = absorb_control_words(c, c->pending_reblocked, reblocked);
+    int32_t rb = 0;
+    int rc = absorb_control_words(c, c->pending_reblocked, &rb);
+    c->last_reblocked = rb != 0;
+    if (reblocked) *reblocked = rb;
     if (rc != GPRF_OK) return rc;
     const int32_t *info = c->h_res.p + CTL_WORDS;
     int bad = -1;
@@ -629,7 +633,7 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
                 double *gradC_out, int32_t *first_bad_unit, bool reblock, int32_t *reblocked) {
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
-    size_t nout = 1 + nx + c->ncov;
+    size_t nout = 1 + nx + c->ncov + 2;
     memcpy(c->h_X.p, X, nx * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
     int any_reblocked = 0;
@@ -689,7 +693,7 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
         delete c;
         return GPRF_ERR_HIP;
     }
-    size_t nout = 1 + (size_t)n * dx + c->ncov;
+    size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
     if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
         c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
         c->h_out.reserve(nout) != hipSuccess) {
@@ -1088,6 +1092,12 @@ int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
     refresh_host_units(c);
     if (flops) *flops = c->work_flops;
     if (fill_bytes) *fill_bytes = c->work_fill_bytes;
+    return GPRF_OK;
+}
+
+int gprf_last_reblocked(const gprf_ctx *c, int32_t *reblocked) {
+    if (!c || !reblocked) return GPRF_ERR_ARG;
+    *reblocked = c->last_reblocked ? 1 : 0;
     return GPRF_OK;
 }
 

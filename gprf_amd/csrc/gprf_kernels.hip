@@ -2150,7 +2150,7 @@ __global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl) {
 // ------------------------------------------------------------------------------------------------
 // Assembly (gprf.py:253-288): Bethe-weighted sums, deterministic gather (no float atomics).
 // block 0: ll and gradC; blocks >= 1: gradX, one thread per (point, coordinate).
-// out = [ll | gradX (n x dx) | gradC (2 + ndfn)]
+// out = [ll | gradX (n x dx) | gradC (2 + ndfn) | overflow flag | units not PD]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
                                                   int want_gx, int want_gc, double *out) {
@@ -2158,9 +2158,13 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
     if (blockIdx.x == 0) {
         __shared__ double red[256][6];
         double acc[6] = {0, 0, 0, 0, 0, 0};
+        __shared__ int s_notpd;
+        if (threadIdx.x == 0) s_notpd = 0;
+        __syncthreads();
         for (int u = threadIdx.x; u < ut.n_units; u += 256) {
             int m = ut.m[u];
             double w = ut.weight[u];
+            if (pl.info[u] != 0) atomicAdd(&s_notpd, 1);
             if (m > 0) {
                 const double *zp = pl.zzpart + (size_t)u * 4;
                 double zz = (zp[0] + zp[1]) + (zp[2] + zp[3]);
@@ -2194,6 +2198,10 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
             int ncov = 2 + kp.ndfn;
             double *gc = out + 1 + (size_t)n * dx;
             for (int t = 0; t < ncov; ++t) gc[t] = want_gc ? red[0][1 + t] : 0.0;
+            // two status words behind the result, so that a caller who SUM-all-reduces the vector over ranks learns in
+            // the same collective whether any rank has to repeat (workspace outgrown) or to jitter (a unit not PD)
+            gc[ncov] = at.ctl[CTL_OVERFLOW] ? 1.0 : 0.0;
+            gc[ncov + 1] = (double)s_notpd;
         }
         return;
     }

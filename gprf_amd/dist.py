@@ -1,25 +1,32 @@
 """One-process-per-GPU evaluation of the GPRF objective: units (blocks and block pairs) are independent given
 (X, Y, theta) — the reference already maps them over a process pool (gprf.py:218-233) and combines them by a
 weighted sum (gprf.py:253-288) — so each rank evaluates its share of the units
-(``gprf_set_shard`` / ``gprf_partition_units``) into a dense partial ``[ll | gradX | gradC]`` vector and ONE
-``all_reduce(SUM)`` (RCCL over xGMI on GPUs; gloo in the CPU tests) combines them.
+(``gprf_set_shard`` / ``gprf_partition_units``) into a dense partial ``[ll | gradX | gradC | status]`` vector and ONE
+``all_reduce(SUM)`` (RCCL over xGMI on GPUs; gloo in the CPU tests) combines them.  The two status words at the end of
+the vector (workspace outgrown on some rank / units not positive definite on some rank) ride in the same collective,
+so every rank takes the same decision — repeat, jitter, raise — without a second exchange on the common path.
 
-``torch`` is plumbing here: device buffers, the stream the kernels are enqueued on, and
-``torch.distributed``.
+``torch`` is plumbing here: device buffers, the stream the kernels are enqueued on, and ``torch.distributed``.
 """
 import numpy as np
 
 from . import _capi
 
+N_STATUS = 2      # status words behind [ll | gradX | gradC] (include/gprf_hip.h, gprf_eval_device)
+
+
+def out_len(n, dx, ncov):
+    return 1 + n * dx + ncov + N_STATUS
+
 
 def pack_out(ll, gX, gC, n, dx, ncov):
-    """[ll | gradX row-major | gradC] — the layout gprf_eval_device writes (include/gprf_hip.h)."""
-    buf = np.zeros(1 + n * dx + ncov)
+    """[ll | gradX row-major | gradC | 0 0] — the layout gprf_eval_device writes (include/gprf_hip.h)."""
+    buf = np.zeros(out_len(n, dx, ncov))
     buf[0] = ll
     if gX is not None and gX.size:
         buf[1:1 + n * dx] = np.asarray(gX).reshape(-1)
     if gC is not None and np.size(gC):
-        buf[1 + n * dx:] = np.asarray(gC).reshape(-1)
+        buf[1 + n * dx:1 + n * dx + ncov] = np.asarray(gC).reshape(-1)
     return buf
 
 
@@ -42,24 +49,26 @@ def local_units(block_idxs, neighbors, dy, rank, world):
     return np.nonzero(owner == rank)[0]
 
 
-def allreduce_sum_(t, group=None):
-    """The one collective of an evaluation."""
+def _active(group=None):
     import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size(group) > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1"):
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(group) > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1")
+
+
+def allreduce_sum_(t, group=None):
+    """The one collective of an evaluation."""
+    import torch.distributed as dist
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
 def allreduce_sum_async_(t, group=None):
     """The same collective, asynchronously: returns the work handle (``None`` when there is nothing to reduce).
-    ``handle.wait()`` makes the CURRENT stream wait for the result, it does not block the host: consecutive,
-    independent evaluations keep the compute stream busy while the previous partials are still on the wire."""
-    import os
+    ``handle.wait()`` makes the CURRENT stream wait for the result, it does not block the host."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size(group) > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1"):
+    if _active(group):
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
@@ -77,10 +86,35 @@ def agree_first_bad(bad, group=None, device=None):
     return -1 if v == big else v
 
 
+def jitter_schedule(evaluate, first_bad, n_units, diag_mean, start=None):
+    """jitchol's policy (gpy_linalg.py:81-97) per failing unit: require a positive diagonal, then retry on K + j I with
+    j = mean(diag K) * 1e-6 * 10^k, k = 0..4, else LinAlgError.  ``evaluate(jitter) -> (result, bad)`` runs one
+    evaluation with the per-unit jitter vector and returns the lowest failing unit id (-1 = none) — in a sharded run
+    the id every rank agreed on, so that all ranks walk the same schedule."""
+    from collections import defaultdict
+    if not (diag_mean > 0.):
+        raise _capi.NotPositiveDefinite("not pd: non-positive diagonal elements", first_bad)
+    jitter = np.zeros(n_units) if start is None else np.array(start, dtype=np.float64)
+    tries = defaultdict(int)
+    bad = first_bad
+    while True:
+        k = tries[bad]
+        if k >= 5:
+            raise _capi.NotPositiveDefinite("not positive definite, even with jitter.", bad)
+        jitter[bad] = diag_mean * 1e-6 * 10.0 ** k
+        tries[bad] += 1
+        result, bad = evaluate(jitter)
+        if bad < 0:
+            return result, jitter
+
+
 class DeviceEvaluator(object):
-    """Device-resident evaluation loop over one GPRF context: X and the output vector live in HBM (torch
-    tensors), kernels are enqueued on torch's current stream, and with world > 1 the partial outputs are
-    all-reduced in place.  This is the timed region of bench.py."""
+    """Evaluation loop over one (sharded) GPRF context with X and the output vector in HBM (torch tensors): kernels on
+    a torch stream, the partial outputs all-reduced in place when world > 1.
+
+    ``evaluate`` is the optimiser-visible call — host X in, host (ll, gradX, gradC) out, the re-blocking of update_X
+    and the all-reduce inside, nothing of the next evaluation overlapping it.  ``enqueue`` / ``result`` are the
+    device-resident halves (bench.py's pipelined side figure, tests)."""
 
     def __init__(self, gprf, group=None):
         import torch
@@ -90,27 +124,32 @@ class DeviceEvaluator(object):
         ctx = gprf._ctx
         self.n, self.dx, self.ncov = ctx.n, ctx.dx, ctx.ncov
         dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
         # a real (non-null) stream: the kernels, the RCCL all-reduce and torch's events all sit on it
         self.stream = torch.cuda.Stream(device=dev)
-        self.d_X = torch.empty(self.n * self.dx, dtype=torch.float64, device=dev)
-        self.d_out = torch.empty(1 + self.n * self.dx + self.ncov, dtype=torch.float64, device=dev)
+        nx, no = self.n * self.dx, out_len(self.n, self.dx, self.ncov)
+        self.d_X = torch.empty(nx, dtype=torch.float64, device=dev)
+        self.d_out = torch.empty(no, dtype=torch.float64, device=dev)
+        self.h_X = torch.empty(nx, dtype=torch.float64, pin_memory=True)
+        self.h_out = torch.empty(no, dtype=torch.float64, pin_memory=True)
         self._work = None              # the all-reduce still in flight on d_out, if any
 
     def set_X(self, X):
         with self.torch.cuda.stream(self.stream):
-            self.d_X.copy_(self.torch.as_tensor(np.ascontiguousarray(X, dtype=np.float64).reshape(-1)))
+            self.h_X.numpy()[:] = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
+            self.d_X.copy_(self.h_X, non_blocking=True)
         self.stream.synchronize()
 
-    def enqueue(self, grad_X=True, grad_cov=False, stream=None):
+    def enqueue(self, grad_X=True, grad_cov=False, stream=None, reblock=False):
         """Enqueue one evaluation (+ the all-reduce) on ``stream`` (default: this evaluator's own);
         returns immediately."""
         st = self.stream if stream is None else stream
         with self.torch.cuda.stream(st):
             if self._work is not None:
                 self._work.wait()      # the stream (not the host) waits before d_out is overwritten
-            self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream)
-            # asynchronous: RCCL runs on its own stream behind this evaluation's kernels; the next (independent)
-            # evaluation enqueued on `st` does not wait for it
+            self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream,
+                                    reblock=reblock)
+            # asynchronous: RCCL runs on its own stream behind this evaluation's kernels
             self._work = allreduce_sum_async_(self.d_out, self.group)
 
     def wait(self):
@@ -125,16 +164,70 @@ class DeviceEvaluator(object):
         rc, bad = self.g._ctx.eval_status()
         if rc == _capi.GPRF_NOT_PD:
             raise _capi.NotPositiveDefinite("unit %d: kernel matrix not positive definite" % bad, bad)
+        if rc == _capi.GPRF_RETRY:
+            raise _capi.GprfHipError("the re-partition outgrew the workspace; enqueue the evaluation again")
         return unpack_out(self.d_out.cpu().numpy(), self.n, self.dx, self.ncov, grad_X, grad_cov)
+
+    # ------------------------------------------------------------------ the optimiser-visible call
+    def _round(self, grad_X, grad_cov, reblock):
+        """one evaluation + all-reduce + download, fully finished: -> (host vector, local status, local bad unit)"""
+        torch, st = self.torch, self.stream
+        with torch.cuda.stream(st):
+            self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream,
+                                    reblock=reblock)
+            allreduce_sum_(self.d_out, self.group)
+            self.h_out.copy_(self.d_out, non_blocking=True)
+        st.synchronize()
+        rc, bad = self.g._ctx.eval_status()
+        return self.h_out.numpy(), rc, bad
+
+    def evaluate(self, X, grad_X=False, grad_cov=False, reblock=False):
+        """-> (ll, gradX, gradC, reblocked) with jitchol's retry applied identically on every rank."""
+        torch, st = self.torch, self.stream
+        with torch.cuda.stream(st):
+            self.h_X.numpy()[:] = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
+            self.d_X.copy_(self.h_X, non_blocking=True)
+        g = self.g
+        no = out_len(self.n, self.dx, self.ncov)
+
+        def run(reblock_now):
+            # repeat while ANY rank's new partition outgrew its workspace (that rank has grown it by now)
+            for _ in range(4):
+                buf, rc, bad = self._round(grad_X, grad_cov, reblock_now)
+                if reblock_now and g._ctx.last_reblocked():
+                    reblocked[0] = True
+                if buf[no - 2] == 0.0:
+                    return buf, bad
+                reblock_now = False
+            raise _capi.GprfHipError("the unit tables did not fit the workspace after growing it three times")
+
+        reblocked = [False]
+        buf, bad = run(reblock)
+        reblocked = reblocked[0]
+        if buf[no - 1] != 0.0:
+            # some unit on some rank is not positive definite: every rank learns the lowest such unit and walks the
+            # same jitter schedule (ADVICE r1: no rank may return NaN while another raises)
+            n_units = g.n_blocks + len(g._nbrs_pushed)
+            diag_mean = g.cov.wfn_params[0] + g.noise_var
+
+            def ev(jitter):
+                g._ctx.set_unit_jitter(jitter)
+                g._jitter = jitter
+                b, bd = run(False)
+                return b, (agree_first_bad(bd, self.group, self.dev) if b[no - 1] != 0.0 else -1)
+
+            buf, _ = jitter_schedule(ev, agree_first_bad(bad, self.group, self.dev), n_units, diag_mean)
+        ll, gX, gC = unpack_out(buf, self.n, self.dx, self.ncov, grad_X, grad_cov)
+        return ll, gX, gC, reblocked
 
 
 def distributed_llgrad(gprf, grad_X=False, grad_cov=False, group=None, evaluator=None):
     """``GPRF.llgrad`` for a sharded GPRF (constructed with ``shard=(rank, world)``): local partial sums,
-    then one all-reduce.  Every rank returns the full (ll, gradX, gradCov)."""
+    then one all-reduce.  Every rank returns the full (ll, gradX, gradCov).  (``GPRF.llgrad`` itself does this when
+    torch.distributed is initialised with more than one rank; this form takes an explicit group / evaluator.)"""
     if evaluator is None:
         evaluator = DeviceEvaluator(gprf, group)
     gprf._push_blocks()
     gprf._push_neighbors(gprf.neighbors)
-    evaluator.set_X(gprf.X)
-    evaluator.enqueue(grad_X, grad_cov)
-    return evaluator.result(grad_X, grad_cov)
+    ll, gX, gC, _ = evaluator.evaluate(gprf.X, grad_X, grad_cov, reblock=False)
+    return ll, gX, gC

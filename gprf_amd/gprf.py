@@ -38,10 +38,14 @@ class GPRF(object):
 
     def __init__(self, X, Y, block_fn, cov, noise_var, kernelized=False, dy=None,
                  neighbor_threshold=1e-3, nonstationary=False, nonstationary_prec=False,
-                 block_idxs=None, neighbors=None, device=0, shard=None):
+                 block_idxs=None, neighbors=None, device=0, shard=None, group=None, reduce=True):
         """Arguments as gprf.py:85-87.  ``kernelized`` / ``nonstationary`` are dead or broken branches in
         the reference (Appendix A.9/11) and are refused.  ``device`` = HIP device
-        ordinal; ``shard`` = (rank, world) to evaluate only this rank's share of the units."""
+        ordinal.  ``shard`` = (rank, world): this object evaluates only its rank's share of the units and ``llgrad``
+        all-reduces the partial sums over the torch.distributed ``group`` (one process per GPU; the counterpart of
+        the reference's process-pool fan-out inside llgrad, gprf.py:218-233), so every rank returns the full result
+        and an optimiser can run unchanged on all ranks.  ``reduce=False`` returns the rank's partial sums instead
+        (tests, callers that reduce themselves)."""
         if kernelized or nonstationary or nonstationary_prec:
             raise NotImplementedError("kernelized / nonstationary GPRF variants are unreachable in the "
                                       "reference (gprf.py:90-97,302) and are not provided")
@@ -69,8 +73,10 @@ class GPRF(object):
         n, dx = X.shape
         self._ctx = _capi.Context(n, dx, Y.shape[1], _capi.DIST_IDS[cov.dfn_str], _capi.KERN_IDS[cov.wfn_str],
                                   device=device)
+        self._shard = (int(shard[0]), int(shard[1])) if shard is not None else (0, 1)
+        self._group, self._reduce, self._dist_eval = group, bool(reduce), None
         if shard is not None:
-            self._ctx.set_shard(int(shard[0]), int(shard[1]))
+            self._ctx.set_shard(*self._shard)
         self._ctx.set_Y(Y)
         self._push_theta()
         self._blocks_pushed = None
@@ -234,6 +240,8 @@ class GPRF(object):
         self._push_neighbors(neighbors)
 
         X = np.ascontiguousarray(self.X, dtype=np.float64)
+        if self._shard[1] > 1 and self._reduce:
+            return self._llgrad_sharded(X, grad_X, grad_cov)
         if self._reblock_pending:
             # update_X's re-blocking and the evaluation in one library call
             rc, ll, gX, gC, bad, reblocked = self._ctx.update_eval(X, grad_X, grad_cov)
@@ -250,27 +258,40 @@ class GPRF(object):
         gradCov = gC.reshape((1, -1)) if grad_cov else np.zeros((0, 0))
         return ll, gradX, gradCov
 
+    def _llgrad_sharded(self, X, grad_X, grad_cov):
+        """This rank's units on this GPU, ONE all-reduce (sum) over the ranks, the same result on every rank."""
+        from . import dist as gdist
+        import torch.distributed as tdist
+        if not (tdist.is_available() and tdist.is_initialized()):
+            raise RuntimeError("GPRF(shard=(%d, %d)).llgrad needs torch.distributed initialised (one process per GPU); "
+                               "pass reduce=False for this rank's partial sums" % self._shard)
+        if tdist.get_world_size(self._group) != self._shard[1]:
+            raise RuntimeError("shard world %d != process group size %d" % (self._shard[1], tdist.get_world_size(self._group)))
+        if self._dist_eval is None:
+            self._dist_eval = gdist.DeviceEvaluator(self, self._group)
+        ll, gX, gC, reblocked = self._dist_eval.evaluate(X, grad_X, grad_cov, reblock=self._reblock_pending)
+        self._reblock_pending = False
+        if reblocked:
+            self._block_of, self._block_idxs = None, None
+            self._blocks_pushed = "device"
+        return ll, gX, gC
+
     def _retry_with_jitter(self, X, grad_X, grad_cov, bad):
         """jitchol's policy (gpy_linalg.py:81-97) applied per failing unit: require a positive diagonal,
         then retry on K + j I with j = mean(diag K) * 1e-6 * 10^k, k = 0..4; the factor of the jittered
         matrix is then used for everything.  diag K = sv + nv for both kernels."""
+        from .dist import jitter_schedule
         n_units = self.n_blocks + len(self._nbrs_pushed)
         diag_mean = self.cov.wfn_params[0] + self.noise_var
-        if not (diag_mean > 0.):
-            raise _capi.NotPositiveDefinite("not pd: non-positive diagonal elements", bad)
-        jitter = np.zeros(n_units) if self._jitter is None else self._jitter.copy()
-        tries = defaultdict(int)
-        while True:
-            k = tries[bad]
-            if k >= 5:
-                raise _capi.NotPositiveDefinite("not positive definite, even with jitter.", bad)
-            jitter[bad] = diag_mean * 1e-6 * 10.0 ** k
-            tries[bad] += 1
+
+        def ev(jitter):
             self._ctx.set_unit_jitter(jitter)
             self._jitter = jitter
-            rc, ll, gX, gC, bad = self._ctx.eval(X, grad_X, grad_cov)
-            if rc == _capi.GPRF_OK:
-                return rc, ll, gX, gC
+            rc, ll, gX, gC, b = self._ctx.eval(X, grad_X, grad_cov)
+            return (rc, ll, gX, gC), (b if rc == _capi.GPRF_NOT_PD else -1)
+
+        (rc, ll, gX, gC), _ = jitter_schedule(ev, bad, n_units, diag_mean, self._jitter)
+        return rc, ll, gX, gC
 
     # reference attribute names some callers read
     @property

@@ -143,8 +143,11 @@ int gprf_update_eval(gprf_ctx *ctx, const double *X, int32_t want_gradX, int32_t
                      double *gradX_out, double *gradC_out, int32_t *first_bad_unit, int32_t *reblocked);
 
 /* Same evaluation with device-resident input and output (the timed form; also what a multi-GPU caller
- * all-reduces).  d_X: n*dx doubles in HBM.  d_out: 1 + n*dx + ntheta doubles in HBM laid out
- * [ll | gradX row-major | gradC]; gradX / gradC parts are zero-filled when not requested.
+ * all-reduces).  d_X: n*dx doubles in HBM.  d_out: 1 + n*dx + ntheta + 2 doubles in HBM laid out
+ * [ll | gradX row-major | gradC | s0 | s1]; gradX / gradC parts are zero-filled when not requested.  s0 = 1 if this
+ * context's re-partition outgrew its workspace (GPRF_RETRY will be reported), s1 = number of this context's units
+ * that were not positive definite: after a SUM all-reduce of the vector every rank knows whether ANY rank has to
+ * repeat or to jitter, in the same collective that sums the objective.
  * stream: a hipStream_t (NULL = the context's own stream); the call only enqueues work.
  * Follow with gprf_eval_status() after synchronising the stream. */
 int gprf_eval_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX, int32_t want_gradC,
@@ -158,6 +161,8 @@ int gprf_update_eval_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX
  * new partition is installed — enqueue the evaluation again with gprf_eval_device.  (The host forms gprf_eval /
  * gprf_update_eval do that themselves.) */
 int gprf_eval_status(gprf_ctx *ctx, int32_t *first_bad_unit);
+/* Whether the evaluation gprf_eval_status last finished changed the partition (host-side flag, no device access). */
+int gprf_last_reblocked(const gprf_ctx *ctx, int32_t *reblocked);
 
 /* Bookkeeping a caller may want. */
 int gprf_num_units(const gprf_ctx *ctx, int32_t *n_units_total, int32_t *n_units_local);

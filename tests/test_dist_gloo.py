@@ -93,7 +93,7 @@ def test_pack_unpack_roundtrip():
     gX = np.arange(12.0).reshape(6, 2)
     gC = np.array([1.0, 2.0, 3.0, 4.0])
     buf = gdist.pack_out(-3.5, gX, gC, 6, 2, 4)
-    assert buf.shape == (1 + 12 + 4,)
+    assert buf.shape == (1 + 12 + 4 + 2,)
     ll, a, b = gdist.unpack_out(buf, 6, 2, 4, True, True)
     assert ll == -3.5 and np.array_equal(a, gX) and np.array_equal(b, gC.reshape(1, -1))
     ll, a, b = gdist.unpack_out(buf, 6, 2, 4, False, False)
