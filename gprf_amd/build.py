@@ -28,6 +28,9 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
+           # k_potrf_reg keeps tiles in explicitly numbered AGPRs behind inline asm: the compiler must never park a
+           # spilled VGPR in an AGPR of its own choosing (tests/test_isa_invariants.py checks the ISA)
+           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
            "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
     # diagnostic builds: GPRF_BUILD_DEFS="-DGPRF_PROFILE" compiles the in-kernel cycle stamps in
     cmd[1:1] = os.environ.get("GPRF_BUILD_DEFS", "").split()

@@ -50,21 +50,27 @@ struct DevBuf {
 
 template <typename T>
 struct PinBuf {
-    T *p = nullptr;
+    T *p = nullptr;      // host address
+    T *d = nullptr;      // the same memory as the device sees it (kernels read / write it directly: zero-copy I/O)
     size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = d = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 64;
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
+        // pinned, mapped into the device's address space, coherent (fine-grained): what a kernel wrote is visible to
+        // the host once the stream has been synchronised
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer((void **)&d, (void *)p, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p); p = d = nullptr; return e; }
+        cap = want;
         return e;
     }
     void release() {
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = d = nullptr;
         cap = 0;
     }
 };
@@ -75,6 +81,8 @@ struct gprf_ctx {
     int n = 0, dx = 0, dy = 0, dist_id = 0, kern_id = 0, device = 0, ndfn = 0, ncov = 0;
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // second queue: the Cholesky instantiation that runs beside the main one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     // host-side model state (what the reference keeps on the GPRF object)
@@ -88,12 +96,15 @@ struct gprf_ctx {
     std::vector<int32_t> h_bsize, h_assign_host, h_posb_host;
     bool host_blocks_dirty = false;       // h_assign_host / h_posb_host / h_bsize wait to be uploaded
     bool static_dirty = true;             // neighbour list / shard / block count changed
+    bool owner_dirty = true;              // ... in a way that re-deals the units over the ranks
+    std::vector<int> owner;               // rank of every unit (global ids)
     bool jitter_dirty = false;
     bool need_build = true;               // the device tables must be rebuilt at the next enqueue, changed or not
     bool assign_valid = false;            // d_assign holds the partition the device tables were built from
 
     // local units (static part; sizes / offsets mirror the device tables only on demand: refresh_host_units)
     int n_local = 0, max_T = 0;           // max_T: the launch-wide bound
+    int shrink_votes = 0;                 // consecutive re-partitions whose largest unit was below the bound
     int64_t cap_rows = 0, cap_mat = 0;
     std::vector<int32_t> l_global, l_bi, l_bj, l_m, l_rowoff;
     std::vector<int64_t> l_matoff;
@@ -104,6 +115,8 @@ struct gprf_ctx {
     DevBuf<double> d_X, d_Y, d_out;
     template <typename T> struct View { T *p = nullptr; };
     View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
+    DevBuf<int32_t> d_big_list, d_small_list;
+    int grid_big = 0, grid_small = 0;     // launch sizes of the Cholesky's two lists (list lengths at the last sync + slack)
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
@@ -119,8 +132,13 @@ struct gprf_ctx {
     DevBuf<int32_t> d_tleft, d_tright, d_tleaf;
     int tree_nodes = 0, tree_dim = 0, tree_wrap = 0;
     int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
+    bool debug_mode = false;              // inside gprf_debug_run: also store the per-unit-row gradient slab (k_gx_finalize)
     DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
+    PinBuf<int32_t> h_done;               // [0]: sequence number of the last finished host-io evaluation (k_done)
+    int32_t done_seq = 0;
+    bool poll_pending = false;            // the pending evaluation ends with k_done: finish_eval may poll
+    bool spin = true;                     // GPRF_SYNC=block: hipStreamSynchronize instead of polling
 
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
@@ -135,6 +153,7 @@ struct gprf_ctx {
     double stage_ms_last[GPRF_N_STAGES] = {};
     bool eval_pending = false;
     bool pending_reblocked = false;       // the pending evaluation ran the partition kernel
+    int epoch = 0, pending_epoch = 0;     // evaluation counter the partition kernels stamp ctl[CTL_CHANGED] with
     bool last_reblocked = false;          // ... and the last finished one changed the partition
     hipStream_t last_stream = nullptr;    // stream of the last enqueue (gprf_eval_status synchronises it)
     hipEvent_t ev_tables = nullptr;       // recorded on the context stream after a table upload
@@ -173,6 +192,8 @@ UnitTab make_tab(gprf_ctx *c) {
     t.max_T = c->max_T;
     t.ids = c->d_ids.p;
     t.n_ids = c->n_local;
+    t.big_list = c->d_big_list.p; t.small_list = c->d_small_list.p; t.ctl = c->d_res.p;
+    t.grid_big = c->grid_big; t.grid_small = c->grid_small;
     return t;
 }
 
@@ -181,7 +202,11 @@ BuildTab make_build(gprf_ctx *c) {
     b.assign = c->d_assign.p; b.posb = c->d_posb.p; b.rank = c->d_rank.p; b.cnt = c->d_cnt.p;
     b.bsize = res_bsize(c);
     b.unit_bi = c->d_unit_bi.p; b.unit_bj = c->d_unit_bj.p; b.bu_ptr = c->d_bu_ptr.p; b.bu_ent = c->d_bu_ent.p;
+    b.ids = c->d_ids.p; b.big_list = c->d_big_list.p; b.small_list = c->d_small_list.p;
+    b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE && potrf_dual_enabled()) ? potrf_small_maxT() : 0;
+    b.grid_big = c->grid_big; b.grid_small = c->grid_small;
     b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
+    b.Xu = c->d_Xu.p; b.xstride = c->dist_id == GPRF_DIST_LLD ? 8 : XPAD;
     b.ctl = res_ctl(c);
     b.n = c->n; b.n_blocks = c->n_blocks; b.n_local = c->n_local; b.n_chunks = c->n_chunks;
     b.cap_rows = c->cap_rows; b.cap_mat = c->cap_mat; b.maxT_bound = c->max_T;
@@ -224,6 +249,13 @@ void refresh_host_units(gprf_ctx *c) {
     }
     c->cur_rows = rows; c->cur_mat = mat;
     c->work_flops = flops; c->work_fill_bytes = fbytes;
+    // launch sizes of the Cholesky's two lists: the present lengths + slack, followed down only when far above
+    int nbig = 0;
+    for (int l = 0; l < nl; ++l) nbig += pad16(c->l_m[l]) / 16 > potrf_small_maxT() ? 1 : 0;
+    // (surplus workgroups of the large-unit launch take small units, see potrf_reg_body: slack costs nothing there; the
+    // small-unit launch simply covers every unit)
+    if (nbig + 8 > c->grid_big || nbig + 96 < c->grid_big) c->grid_big = std::min(nl, nbig + 32);
+    c->grid_small = nl;
 }
 
 // workspace for `rows` padded rows, `mat` matrix elements and units of up to maxT tiles per edge
@@ -305,8 +337,14 @@ int rebuild_static(gprf_ctx *c) {
         }
     // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy, on the sizes of THIS partition;
     // the ownership then stays until the next static rebuild (later re-blockings on the device keep it)
-    std::vector<int> owner(nu, 0);
-    if (c->world > 1 && nu > 0) gprf_partition_units(nu, um.data(), c->dy, c->world, owner.data());
+    // (a rebuild that only refreshes the launch lists — a unit changed size class — keeps the ownership: ranks do not
+    // rebuild in lockstep then)
+    std::vector<int> &owner = c->owner;
+    if (c->owner_dirty || (int)owner.size() != nu) {
+        owner.assign((size_t)nu, 0);
+        if (c->world > 1 && nu > 0) gprf_partition_units(nu, um.data(), c->dy, c->world, owner.data());
+        c->owner_dirty = false;
+    }
     c->l_global.clear(); c->l_bi.clear(); c->l_bj.clear();
     std::vector<double> weight, jitter;
     for (int u = 0; u < nu; ++u) {
@@ -351,6 +389,8 @@ int rebuild_static(gprf_ctx *c) {
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_offj.reserve(nl1));
     HIP_TRY(c, c->d_matoff.reserve(nl1));
+    HIP_TRY(c, c->d_big_list.reserve(nl1));
+    HIP_TRY(c, c->d_small_list.reserve(nl1));
     HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1, 1.0));
     HIP_TRY(c, c->d_posb.reserve((size_t)c->n + 1, 1.0));
     HIP_TRY(c, c->d_rank.reserve((size_t)c->n + 1, 1.0));
@@ -488,13 +528,15 @@ int enqueue_partition(gprf_ctx *c, const double *d_X, hipStream_t s) {
     if (c->n_centers != c->n_blocks) return fail(c, GPRF_ERR_STATE, "the centres / tree leaves do not match the block count");
     BuildTab bt = make_build(c);
     if (!c->assign_valid) HIP_TRY(c, hipMemsetAsync(c->d_assign.p, 0xff, (size_t)c->n * sizeof(int32_t), s));
-    HIP_TRY(c, hipMemsetAsync(res_ctl(c) + CTL_CHANGED, 0, sizeof(int32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, (size_t)c->n_chunks * c->n_blocks * sizeof(int32_t), s));
+    c->epoch = c->epoch >= 0x3fffffff ? 1 : c->epoch + 1;
+    // (the partition kernel leaves a copy of the points in d_X when they came from somewhere else — pinned host
+    // memory in the host-in / host-out form: the kernels behind it read HBM)
+    double *xcopy = d_X == c->d_X.p ? nullptr : c->d_X.p;
     if (c->tree_nodes > 0)
-        launch_route(d_X, c->dx, c->tree_dim, c->tree_wrap, c->d_tvec.p, c->d_tcenter.p, c->d_tsplit.p, c->d_tleft.p,
-                     c->d_tright.p, c->d_tleaf.p, bt, s);
+        launch_route(d_X, xcopy, c->dx, c->tree_dim, c->tree_wrap, c->d_tvec.p, c->d_tcenter.p, c->d_tsplit.p, c->d_tleft.p,
+                     c->d_tright.p, c->d_tleaf.p, bt, c->epoch, s);
     else
-        launch_assign(d_X, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, bt, s);
+        launch_assign(d_X, xcopy, c->dx, c->d_cs.p, c->d_c2.p, c->n_centers, bt, c->epoch, s);
     c->assign_valid = true;
     return GPRF_OK;
 }
@@ -502,7 +544,7 @@ int enqueue_partition(gprf_ctx *c, const double *d_X, hipStream_t s) {
 // enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug); reblock: first
 // re-partition the points on the device (update_X's block_fn, gprf.py:171-172)
 int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
-                 int stop_after, bool reblock) {
+                 int stop_after, bool reblock, bool host_io = false) {
     int rc = prepare(c, s);
     if (rc != GPRF_OK) return rc;
     bool tm = c->timing;
@@ -523,26 +565,33 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     int stage = 0;
     auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[slot][stage], s); ++stage; };
     mark();      // stage "gather" = re-partition + table build (when asked for) + the coordinate gather
+    int from_chunks = 0, force = c->need_build ? 1 : 0;
     if (reblock) {
         rc = enqueue_partition(c, d_X, s);
         if (rc != GPRF_OK) return rc;
-        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, s);
+        if (d_X != c->d_X.p) d_X = c->d_X.p;      // the partition kernel's copy
+        from_chunks = 1;
+        launch_build_tables(make_build(c), 1, force, c->epoch, s);
     } else if (c->need_build) {
-        launch_build_tables(make_build(c), 0, 1, s);
+        launch_build_tables(make_build(c), 0, 1, c->epoch, s);
     }
     c->need_build = false;
+    c->pending_epoch = c->epoch;
     UnitTab ut = make_tab(c);
     Pools pl = make_pools(c);
     KParams kp = make_kparams(c);
-    AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c)};
+    // host_io: d_X / d_out are the pinned host buffers themselves (read / written by the kernels over the fabric) and
+    // the result words are mirrored into pinned memory by the assembly kernel: no copy command in the evaluation
+    AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c),
+                   c->d_res.p, host_io ? c->h_res.d : nullptr, (int)c->res_words};
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
-    launch_gather_x(c->dist_id, ut, pl, d_X, c->dx, s);
+    launch_scatter_x(make_build(c), d_X, c->dx, c->dist_id, from_chunks, force, c->epoch, s);
     mark();
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
     if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
     mark();
-    if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s);
+    if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s, c->stream2, c->ev_fork, c->ev_join);
     mark();
     if (stop_after >= 2) launch_solve(ut, pl, kp, s);
     mark();
@@ -556,8 +605,15 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
     mark();
     HIP_TRY(c, hipGetLastError());
-    // control words, unit status, block sizes -> pinned host: one download
-    HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // control words, unit status, block sizes -> pinned host: one download (or the assembly kernel's mirror)
+    c->poll_pending = false;
+    if (!host_io || stop_after < 5) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    } else if (c->spin && c->h_done.p) {
+        c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
+        launch_done(c->h_done.d, c->done_seq, s);
+        c->poll_pending = true;
+    }
     if (!c->ev_last) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev_last, s));
     c->eval_pending = true;
@@ -570,7 +626,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
 // and returns GPRF_RETRY
 int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
     const int32_t *ctl = c->h_res.p, *bsz = c->h_res.p + CTL_WORDS + c->n_local;
-    bool changed = reblocked_run && ctl[CTL_CHANGED];
+    bool changed = reblocked_run && ctl[CTL_CHANGED] == c->pending_epoch;
     if (reblocked) *reblocked = changed ? 1 : 0;
     if (changed || ctl[CTL_OVERFLOW]) {
         c->h_bsize.assign(bsz, bsz + c->n_blocks);
@@ -592,10 +648,14 @@ int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
         return GPRF_RETRY;
     }
     // keep the launch-wide bound at the present largest unit (it only has to grow through the overflow path)
+    // ... and follows it down only after a run of smaller partitions: an optimiser whose iterates hover around a
+    // tile boundary would otherwise pay a repeated evaluation every time the largest unit crosses it upwards
     if (changed) {
         int maxT = 0;
         for (int l = 0; l < c->n_local; ++l) maxT = std::max(maxT, pad16(c->l_m[l]) / 16);
-        if (maxT < c->max_T) {
+        c->shrink_votes = maxT < c->max_T ? c->shrink_votes + 1 : 0;
+        if (c->shrink_votes >= 8) {
+            c->shrink_votes = 0;
             int rc = size_workspace(c, 0, 0, 0);
             if (rc != GPRF_OK) return rc;
         }
@@ -606,7 +666,24 @@ int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
 // after the stream has been synchronised: GPRF_OK / GPRF_NOT_PD / GPRF_RETRY (the partition outgrew the workspace:
 // it has been grown, enqueue the evaluation again without re-partitioning)
 int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *reblocked) {
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->poll_pending) {
+        // spin on the sequence number k_done stores into pinned memory (bounded: fall back to the runtime's wait)
+        volatile int32_t *flag = c->h_done.p;
+        auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (*flag != c->done_seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfff) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+                HIP_TRY(c, hipStreamSynchronize(s));
+                break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        c->poll_pending = false;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     c->eval_pending = false;
     if (first_bad_unit) *first_bad_unit = -1;
     int32_t rb = 0;
@@ -634,13 +711,14 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
     size_t nout = 1 + nx + c->ncov + 2;
+    // zero-copy: the kernels read X from, and write the result to, pinned host memory directly (160 KB each way at
+    // n = 10000: two fabric round trips instead of three copy commands with their launch latencies)
     memcpy(c->h_X.p, X, nx * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+    (void)nout;
     int any_reblocked = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        int rc = enqueue_eval(c, c->d_X.p, want_gx, want_gc, c->d_out.p, s, 6, reblock);
+        int rc = enqueue_eval(c, c->h_X.d, want_gx, want_gc, c->h_out.d, s, 6, reblock, true);
         if (rc != GPRF_OK) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->h_out.p, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, s));
         int32_t rb = 0;
         rc = finish_eval(c, s, first_bad_unit, &rb);
         any_reblocked |= rb;
@@ -693,13 +771,21 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
         delete c;
         return GPRF_ERR_HIP;
     }
-    size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
-    if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
-        c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
-        c->h_out.reserve(nout) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         gprf_destroy(c);
         return GPRF_ERR_HIP;
     }
+    size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
+    if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
+        c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
+        c->h_out.reserve(nout) != hipSuccess || c->h_done.reserve(16) != hipSuccess) {
+        gprf_destroy(c);
+        return GPRF_ERR_HIP;
+    }
+    c->h_done.p[0] = 0;
+    if (const char *e = getenv("GPRF_SYNC")) c->spin = !(e[0] == 'b');
     *out = c;
     return GPRF_OK;
 }
@@ -711,7 +797,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
-    c->d_posb.release(); c->d_rank.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
+    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
     c->d_cs.release(); c->d_c2.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
@@ -719,12 +805,15 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release();
-    c->h_X.release(); c->h_out.release();
+    c->h_X.release(); c->h_out.release(); c->h_done.release();
     if (c->ev_valid)
         for (int r = 0; r < gprf_ctx::RING; ++r)
             for (int i = 0; i <= GPRF_N_STAGES; ++i) (void)hipEventDestroy(c->ev[r][i]);
     if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;
@@ -786,6 +875,7 @@ int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, con
     c->have_blocks = true;
     // launch order, shard and workspace follow the sizes: redone with every host partition
     c->static_dirty = true;
+    c->owner_dirty = true;
     return GPRF_OK;
 }
 
@@ -939,6 +1029,7 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
         c->host_blocks_dirty = false;
         c->have_blocks = true;
         c->static_dirty = true;
+        c->owner_dirty = true;
         c->assign_valid = false;
     }
     hipStream_t s = c->stream;
@@ -951,8 +1042,10 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
         HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
         rc = enqueue_partition(c, c->d_X.p, s);
         if (rc != GPRF_OK) return rc;
-        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, s);
+        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, c->epoch, s);
+        launch_scatter_x(make_build(c), c->d_X.p, c->dx, c->dist_id, 1, c->need_build ? 1 : 0, c->epoch, s);
         c->need_build = false;
+        c->pending_epoch = c->epoch;
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -979,6 +1072,7 @@ int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
     c->n_pairs = n_pairs;
     c->pairs.assign(pairs_ij, pairs_ij + 2 * (size_t)n_pairs);
     c->static_dirty = true;
+    c->owner_dirty = true;
     return GPRF_OK;
 }
 
@@ -1004,6 +1098,7 @@ int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
     c->rank = rank;
     c->world = world;
     c->static_dirty = true;
+    c->owner_dirty = true;
     return GPRF_OK;
 }
 
@@ -1150,7 +1245,9 @@ int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
     memcpy(c->h_X.p, X, nx * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->last_stop_after = stop_after;
+    c->debug_mode = true;
     rc = enqueue_eval(c, c->d_X.p, 1, 1, c->d_out.p, c->stream, stop_after, false);
+    c->debug_mode = false;
     if (rc != GPRF_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->eval_pending = false;

@@ -35,6 +35,11 @@ struct UnitTab {
     int n_ids;               // ... and how many
     int n_units;
     int max_T;               // launch-wide bound on mp/16 (the largest unit at the last synchronised build)
+    // the Cholesky's two launch lists, built on the device with the tables (k_build): units of more than / at most
+    // potrf_small_maxT() tiles, each in the order of ids; their lengths are ctl[CTL_NBIG] / ctl[CTL_NSMALL]
+    const int32_t *big_list, *small_list;
+    const int32_t *ctl;
+    int grid_big, grid_small;   // workgroups the two lists are launched with (the build reports a list that is longer)
 };
 
 // What the device-side table build works from and leaves behind (all device pointers).
@@ -48,25 +53,33 @@ struct BuildTab {
     const int32_t *unit_bj;  // [n_local] second block, -1 for a unary unit
     const int32_t *bu_ptr;   // [n_blocks + 1] CSR: block -> the local units that contain it, ascending unit id ...
     const int32_t *bu_ent;   // ... as 2 * unit + side (side 1 = the block's rows come second in the unit)
+    const int32_t *ids;      // [n_local] launch order (largest first at the last host build)
+    int32_t *big_list, *small_list;   // [n_local] each: the units of more than / at most small_maxT tiles, in ids order
+    int small_maxT;          // 0 = no split
+    int grid_big, grid_small;         // launch sizes the lists must fit
     int32_t *m;              // the UnitTab columns this build writes
     int32_t *row_off;
     int64_t *mat_off;
     int32_t *off_j;          // [n_local] rows of the unit's first block (= where the second block's rows start)
     int32_t *upt;
+    double *Xu;              // the coordinate pool (k_scatter_x) and its row stride in doubles
+    int xstride;
     int32_t *ctl;            // control / result words, CTL_* below
     int n, n_blocks, n_local, n_chunks;
     int64_t cap_rows, cap_mat;   // workspace capacities the build must stay within
     int maxT_bound;              // the launch-wide max_T the evaluation kernels will be launched with
 };
-constexpr int CTL_CHANGED = 0;     // some point changed block (set by k_assign / k_route)
+constexpr int CTL_CHANGED = 0;     // = the epoch of the last evaluation in which some point changed block (k_assign / k_route)
 constexpr int CTL_OVERFLOW = 1;    // the partition does not fit the workspace / the launch bound: every unit got m = 0
 constexpr int CTL_ROWS = 2;        // total padded rows of the partition
 constexpr int CTL_MAXT = 3;        // its largest unit in tiles
 constexpr int CTL_MAXM = 4;        // ... in points
 constexpr int CTL_MAT_LO = 5;      // total matrix elements (64 bit, two words)
 constexpr int CTL_MAT_HI = 6;
+constexpr int CTL_NBIG = 8;        // units of more than small_maxT tiles per edge in this partition (length of big_list)
+constexpr int CTL_NSMALL = 9;      // the others (length of small_list)
 constexpr int CTL_BUILDS = 7;      // table builds since the context was created (tests)
-constexpr int CTL_WORDS = 8;
+constexpr int CTL_WORDS = 10;
 
 // spare doubles behind the last unit's matrix in the U / W / K pools (row-panel loads address whole 64-column
 // chunks; the lanes beyond the unit's edge are masked off, the slack keeps even an unmasked variant in bounds)
@@ -100,22 +113,33 @@ struct AssembleTab {
     const int32_t *bu_ent;
     const int32_t *off_j;
     const int32_t *ctl;
+    // the context's result words [ctl | info | bsize] are mirrored by the assembly kernel into (host-visible) memory,
+    // so that a host-in / host-out evaluation needs no copy command at all; mirror_dst = nullptr: no mirror
+    const int32_t *mirror_src;
+    int32_t *mirror_dst;
+    int mirror_n;
 };
 
 // re-blocking: nearest centre / split-tree descent of every point, with the per-chunk ranks and counts the table
-// build starts from (bt.assign / rank / cnt / ctl[CTL_CHANGED])
-void launch_assign(const double *X, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt, hipStream_t s);
-void launch_route(const double *X, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+// build starts from (bt.assign / rank / cnt; ctl[CTL_CHANGED] = epoch when somebody moved)
+void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt,
+                   int epoch, hipStream_t s);
+void launch_route(const double *X, double *Xcopy, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
-                  const BuildTab &bt, hipStream_t s);
-// unit tables from the partition: sizes, offsets (k_unit_scan), unit row -> point (k_place).  from_chunks: the partition
-// came from launch_assign / launch_route (ranks + per-chunk counts), otherwise bt.posb / bt.bsize were uploaded.
-// force = 0: only when ctl[CTL_CHANGED] is set.
-void launch_build_tables(const BuildTab &bt, int from_chunks, int force, hipStream_t s);
-void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, hipStream_t s);
+                  const BuildTab &bt, int epoch, hipStream_t s);
+// unit tables from the partition (k_build): block sizes from the chunk counts, unit sizes and offsets.  from_chunks: the partition came from launch_assign / launch_route in this evaluation, otherwise
+// bt.posb / bt.bsize are already on the device.  force = 0: only when ctl[CTL_CHANGED] == epoch.
+void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epoch, hipStream_t s);
+// every evaluation: coordinates into the unit rows (+ positions and unit row -> point when rebuilding)
+void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, int from_chunks, int force, int epoch,
+                      hipStream_t s);
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s);
+bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
+int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
+// s2 / ev_fork / ev_join: a second queue (and two events) for the instantiation that runs beside the main one; s2 = nullptr: one launch
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, hipStream_t s2,
+                  hipEvent_t ev_fork, hipEvent_t ev_join);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
@@ -123,5 +147,6 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
+void launch_done(int32_t *flag, int32_t seq, hipStream_t s);
 
 }  // namespace gprf

@@ -39,7 +39,18 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl_xor(x, mask, 64); }
+// wave shuffles from the thread index (workgroups are one-dimensional multiples of 64 here): HIP's __shfl* derive
+// the lane from v_mbcnt, which the compiler hoists out of loops and keeps alive across them — in the register-starved
+// Cholesky instantiation it parked that value in an accumulator register (tests/test_isa_invariants.py)
+__device__ __forceinline__ int shfl_i(int v, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ __forceinline__ double shfl_xor_d(double x, int mask) {
+    int idx = (((int)threadIdx.x & 63) ^ mask) << 2;
+    int lo = __builtin_amdgcn_ds_bpermute(idx, __double2loint(x));
+    int hi = __builtin_amdgcn_ds_bpermute(idx, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 
 __device__ __forceinline__ int pad16(int m) { return (m + 15) & ~15; }
 
@@ -246,36 +257,11 @@ template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = G
 
 // ------------------------------------------------------------------------------------------------
 // gathers (gprf.py:300-302, 314-326: X[idxs], Y[idxs], vstack) into padded per-unit rows.  The coordinates are
-// gathered once per evaluation (k_gather_x, one workgroup per unit: rows >= m are padding and get zeros; upt is
-// only defined below m); the outputs never move: the one kernel that needs a unit's Y rows (the forward
+// scattered once per evaluation from the point side (k_scatter_x, with the re-blocking kernels at the end of this
+// file: a point writes its record into its row of every unit that contains its block; padding rows are zeroed when
+// the tables are built); the outputs never move: the one kernel that needs a unit's Y rows (the forward
 // substitution) reads them through upt from the resident n x dy array, which stays in L2 / the Infinity Cache.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_x(UnitTab ut, const double *__restrict__ X, double *__restrict__ Xu,
-                                                  int dx, int geo) {
-    int u = blockIdx.x;
-    int m = ut.m[u];
-    int mp = pad16(m);
-    int r0 = ut.row_off[u];
-    for (int r = threadIdx.x; r < mp; r += 256) {
-        int row = r0 + r;
-        int pt = r < m ? ut.upt[row] : -1;
-        if (geo) {
-            // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
-            double lon = 0.0, lat = 0.0, z = 0.0;
-            if (pt >= 0) { lon = X[(size_t)pt * dx]; lat = X[(size_t)pt * dx + 1]; z = X[(size_t)pt * dx + 2]; }
-            double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
-            double *g = Xu + (size_t)row * GEO_STRIDE;
-            g[GEO_SLH] = sin(hl); g[GEO_CLH] = cos(hl); g[GEO_SNH] = sin(hn); g[GEO_CNH] = cos(hn); g[GEO_Z] = z;
-            g[5] = 0.0; g[6] = 0.0; g[7] = 0.0;
-            continue;
-        }
-        for (int d = 0; d < XPAD; ++d) {
-            double v = 0.0;
-            if (pt >= 0 && d < dx) v = X[(size_t)pt * dx + d];
-            Xu[(size_t)row * XPAD + d] = v;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K fill (gprf.py:333-343 -> VectorTree.kernel_matrix + nv I): 64x64 tile per workgroup, lane = column
@@ -685,8 +671,11 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
 //   * MFMA f64 16x16x4 result -> same-tuple srcC of the next MFMA: 0        (back-to-back accumulate)
 //   * MFMA f64 16x16x4 result -> VALU / LDS read: 18                        -> atile_settle() / trailing s_nop's
 // ------------------------------------------------------------------------------------------------
+template <int SLOTS>
 __device__ __forceinline__ void atile_reserve() {
-    asm volatile("; accumulator tiles: a[0:255]" ::: "a0", "a1", "a254", "a255");
+    static_assert(SLOTS == 32 || SLOTS == 20, "one clobber list per instantiation");
+    if constexpr (SLOTS == 32) asm volatile("; accumulator tiles: a[0:255]" ::: "a0", "a1", "a254", "a255");
+    else asm volatile("; accumulator tiles: a[0:159]" ::: "a0", "a1", "a158", "a159");
 }
 __device__ __forceinline__ void atile_settle() { asm volatile("s_nop 15\n\ts_nop 3"); }
 
@@ -751,6 +740,7 @@ __device__ __forceinline__ void mfma4_vgpr(d4 &c, const double (&a)[4], const do
 
 constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the register-resident kernel takes
 constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
+constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13, = 16 mod 32
 // ------------------------------------------------------------------------------------------------
 // k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
 // chip (T <= reg_maxT tiles per edge).  The trailing matrix never goes back to memory: the strictly-upper
@@ -770,8 +760,13 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
 // GEN: the kernel matrix is not read from the K pool but GENERATED here from the unit's coordinates (SE kernel):
 // k_fill does not run at all, K never exists in HBM, and the prologue's burst of tile loads (every resident unit
 // at once) becomes arithmetic spread over the launch; k_mgrad<.,.,false> re-evaluates the values it needs.
-template <int RW, int SLOTS, bool GEN>
-__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp) {
+// WPS (waves per SIMD the register budget is cut for): 1 = 512 registers per wave (32 tile slots: units up to 16
+// tiles per edge, one workgroup per CU); 2 = 256 registers per wave (20 tile slots + 96 VGPRs: units up to 13 tiles per
+// edge, TWO workgroups per CU — a unit's factorisation is a latency chain that keeps its SIMDs a quarter busy, so
+// two of them side by side nearly double the CU's throughput).  Units outside [min_T, reg_maxT] are left alone.
+template <int RW, int SLOTS, bool GEN, int WPS>
+__device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &pl, int stamps, int reg_maxT, const KParams &kp,
+                                               int which) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
     extern __shared__ double lds[];
     __shared__ int s_fail;
@@ -779,7 +774,28 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 #ifdef GPRF_PROFILE
     unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
-    int u = ut.ids[blockIdx.x];
+    // which: 0 = every unit of the launch order; 1 / 2 = the device-built list of large / small units
+    // The large-unit launch has grid_big >= |big_list| workgroups; its surplus ones must not idle (a 512-register
+    // workgroup can only be scheduled on an EMPTY CU: waiting for one to drain behind the two-per-CU kernel's residents,
+    // just to exit, would hold back this kernel's completion): they take units from the END of the small list (the
+    // smallest ones; this instantiation handles every size), and the small-unit launch leaves those to them.
+    int u;
+    if (which == 0) {
+        u = ut.ids[blockIdx.x];
+    } else {
+        int nb = ut.ctl[CTL_NBIG], ns = ut.ctl[CTL_NSMALL];
+        int surplus = ut.grid_big > nb ? ut.grid_big - nb : 0;
+        if (surplus > ns) surplus = ns;
+        int bid = blockIdx.x;
+        if (which == 1) {
+            if (bid < nb) u = ut.big_list[bid];
+            else if (bid - nb < surplus) u = ut.small_list[ns - 1 - (bid - nb)];
+            else return;
+        } else {
+            if (bid >= ns - surplus) return;
+            u = ut.small_list[bid];
+        }
+    }
     int m = ut.m[u];
     int mp = pad16(m), T = mp >> 4;
     if (T > reg_maxT) return;             // k_potrf's units
@@ -791,9 +807,12 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     int lr = lane & 15, lg = lane >> 4;
     // fixed panel pitch (an odd multiple of 16 doubles: the k-major MFMA operand reads are conflict free):
     // every LDS row offset below is an instruction immediate
-    constexpr int ldp = POTRF_REG_LDP;
-    double *P0 = lds;                     // [2][16][ldp] row panel j of U in buffer j & 1: a pure-factor wave 0
-    double *Ud = P0 + 2 * 16 * ldp;       //   writes panel j-1 back to global while panel j is being solved
+    // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
+    // solved panel then goes to global memory inside its own step (copy_now below), never from the other buffer
+    constexpr int ldp = WPS == 1 ? POTRF_REG_LDP : POTRF_REG2_LDP;
+    constexpr int NPB = WPS == 1 ? 2 : 1;
+    double *P0 = lds;                     // [NPB][16][ldp] row panel j of U in buffer j & (NPB - 1): a pure-factor wave 0
+    double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
                                           // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *dvals = rdt + 16;             // [16 T]    diagonal of U
@@ -817,6 +836,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     const int head = 4 * ov < total ? 4 * ov : total;
     const bool w0busy = ov > 0;                        // wave 0 owns tiles too
     const bool mine = wave > 0 || w0busy;
+    const bool copy_now = w0busy || WPS == 2;          // the tile-owning waves store a solved panel in its own step
     const int wpos = wave == 0 ? 3 : wave - 1;         // position in the four-way deal; workers: also in the three-way
     const int nhead = (head - wpos + 3) >> 2;          // this wave's tiles of the four-way part (head >= 3 or 0)
     // tiles of this wave among idx < r
@@ -844,7 +864,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         if (shv > SLOTS) shv = SLOTS;
     }
 #define PK(s) __builtin_amdgcn_readlane(pkv, s)
-    atile_reserve();
+    atile_reserve<SLOTS>();
     // GEN: K(row, col) of this unit, exactly k_fill's definition (identity in the padding, noise + jitter on the
     // diagonal); the unit's coordinates wait in LDS
     double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XPAD], GEN only (the launcher sizes the LDS)
@@ -942,7 +962,23 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q];
     };
     auto load_tiles = [&]() {
-        if constexpr (GEN) {
+        if constexpr (GEN && WPS == 2) {
+            // one tile at a time, straight into its numbered accumulator: a runtime loop over this wave's slots (one
+            // copy of the exp() code) and a jump on the wave-uniform slot number (the single panel buffer is too small
+            // to stage batches in)
+#pragma unroll 1
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                int pk[1] = {__builtin_amdgcn_readlane(pkv, sl)};
+                if (pk[0] < 0) break;                // slots are filled from 0 up
+                double kv[1][4];
+                kgen(std::integral_constant<int, 1>{}, pk, kv, -1.0);      // MINUS the trailing tile
+                static_for<0, SLOTS>([&](auto sc) {
+                    constexpr int S = decltype(sc)::value;
+                    if (sl == S) atile_set<S>(kv[0]);
+                });
+            }
+            return;
+        } else if constexpr (GEN) {
             // tiles -> accumulators, 8 slots at a time: a RUNTIME loop evaluates the batch's tiles into this wave's
             // quarter of the (still unused) panel buffers — one copy of the exp() code instead of one per slot, which
             // would not fit the instruction cache — and a static walk moves them into the numbered accumulators
@@ -955,12 +991,19 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
                                  (B0 + i + 1 < SLOTS) ? __builtin_amdgcn_readlane(pkv, B0 + i + 1) : -1};
                     if (pk[0] >= 0) {                // wave-uniform: only the slots this wave really owns
                         double kv[2][4];
-                        if (pk[1] >= 0) {
+                        if (WPS == 1 && pk[1] >= 0) {
                             kgen(std::integral_constant<int, 2>{}, pk, kv, -1.0);   // MINUS the trailing tile
 #pragma unroll
                             for (int q = 0; q < 4; ++q) stage[(i + 1) * 256 + 64 * q + lane] = kv[1][q];
                         } else {
                             kgen(std::integral_constant<int, 1>{}, pk, kv, -1.0);
+                            if (WPS != 1 && pk[1] >= 0) {      // (the 256-register instantiation: one tile at a time)
+                                int pk1[1] = {pk[1]};
+                                double kv1[1][4];
+                                kgen(std::integral_constant<int, 1>{}, pk1, kv1, -1.0);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) stage[(i + 1) * 256 + 64 * q + lane] = kv1[0][q];
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) stage[i * 256 + 64 * q + lane] = kv[0][q];
@@ -1047,29 +1090,33 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
     // for these stores.
     auto copy_panel = [&](int jp, int a0, int da) {
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const double *Pj = P0 + (jp & 1) * 16 * ldp;
+        const double *Pj = P0 + (jp & (NPB - 1)) * 16 * ldp;
         // two columns per lane (16-byte LDS reads and global stores: the copy is instruction-issue bound); the
         // panel starts at a multiple of 16 columns and mp <= 256, so two 128-column chunks cover it
         int c0 = 16 * (jp + 1) + 2 * lane;
         bool in0 = c0 < mp, in1 = c0 + 128 < mp;
-        d2 pv[16][2];
         // every LDS read first, then every store: a read -> wait -> store round trip per row would cost more than
-        // the rest of the step
+        // the rest of the step (in passes of RB rows: the 256-register instantiation cannot hold all sixteen)
+        constexpr int RB = WPS == 1 ? 16 : 4;
+        d2 pv[RB][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int a = a0 + da * r;
-            if (a < 16) {
-                if (in0) pv[r][0] = *(const d2 *)(Pj + a * ldp + c0);
-                if (in1) pv[r][1] = *(const d2 *)(Pj + a * ldp + c0 + 128);
+        for (int r0 = 0; r0 < 16; r0 += RB) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                int a = a0 + da * (r0 + r);
+                if (a < 16) {
+                    if (in0) pv[r][0] = *(const d2 *)(Pj + a * ldp + c0);
+                    if (in1) pv[r][1] = *(const d2 *)(Pj + a * ldp + c0 + 128);
+                }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int a = a0 + da * r;
-            if (a < 16) {
-                double *Urow = U + (size_t)(16 * jp + a) * mp;
-                if (in0) *(d2 *)(Urow + c0) = pv[r][0];
-                if (in1) *(d2 *)(Urow + c0 + 128) = pv[r][1];
+            for (int r = 0; r < RB; ++r) {
+                int a = a0 + da * (r0 + r);
+                if (a < 16) {
+                    double *Urow = U + (size_t)(16 * jp + a) * mp;
+                    if (in0) *(d2 *)(Urow + c0) = pv[r][0];
+                    if (in1) *(d2 *)(Urow + c0 + 128) = pv[r][1];
+                }
             }
         }
     };
@@ -1086,12 +1133,12 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         asm volatile("" : "+v"(shv));
         const int s_lo = j > 0 ? __builtin_amdgcn_readlane(shv, j - 1) : 0;
         const int s_hi = __builtin_amdgcn_readlane(shv, j);
-        P = P0 + (j & 1) * 16 * ldp;
+        P = P0 + (j & (NPB - 1)) * 16 * ldp;
         if (wave == 0) {
             // U_jj (published in LDS by the last look-ahead) -> global, off the critical path
             for (int e = lane; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
             // and, when this wave has no tiles of its own, the previous step's solved row panel
-            if (!w0busy && j > 0) copy_panel(j - 1, 0, 1);
+            if (!copy_now && j > 0) copy_panel(j - 1, 0, 1);
         }
         if (mine) {
             // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
@@ -1126,7 +1173,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
             // of the row), one column per lane
 #pragma unroll 1
             for (int sl = s_lo + lg; __any(sl < s_hi); sl += 4) {
-              int k = __shfl(pkv, sl & 31, 64) & 31;    // (all lanes active here: the source lane may be in any row)
+              int k = shfl_i(pkv, sl & 31) & 31;        // (all lanes active here: the source lane may be in any row)
               if (sl < s_hi) {
                 int col = 16 * k + lr;
                 double x[16];
@@ -1166,7 +1213,8 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
             // the solved row panel -> global U first when wave 0 is a worker too: the stores retire under the
             // MFMA work below
 #ifndef GPRF_ABL_NOCOPY
-            if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution)
+            if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution ...
+            else if (copy_now) copy_panel(j, wave - 1, RW - 1);      // ... or, single-buffered, the three workers now)
             GPRF_STAMP3(0)
             // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % 3
             if (wave > 0)
@@ -1259,7 +1307,7 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         int jt = T - 1;
         for (int e = lane; e < 256; e += 64) U[(size_t)(16 * jt + (e >> 4)) * mp + 16 * jt + (e & 15)] = Ud[e];
     }
-    if (!w0busy && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
+    if (!copy_now && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
     __syncthreads();    // the epilogue reads U_jj back from global
 #ifndef GPRF_ABL_NOEPI
     potrf_epilogue<RW>(U, V, P0, dvals, lred, mp, T, u, pl);
@@ -1270,6 +1318,18 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
         pl.dbg[(size_t)u * 8 + 6] = (double)(__builtin_amdgcn_s_memtime() - t_loopend);
     }
 #endif
+}
+
+// the two kernels around the body (an attribute cannot depend on a template parameter): one workgroup per CU with 512
+// registers per wave, and two per CU with 256 (20 tile slots = a[0:159] + at most 96 VGPRs)
+template <int RW, int SLOTS, bool GEN>
+__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
+    potrf_reg_body<RW, SLOTS, GEN, 1>(ut, pl, stamps, reg_maxT, kp, which);
+}
+template <int RW, int SLOTS, bool GEN>
+__global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg2(UnitTab ut, Pools pl, int stamps,
+                                                                                                int reg_maxT, KParams kp, int which) {
+    potrf_reg_body<RW, SLOTS, GEN, 2>(ut, pl, stamps, reg_maxT, kp, which);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2203,6 +2263,8 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
             gc[ncov] = at.ctl[CTL_OVERFLOW] ? 1.0 : 0.0;
             gc[ncov + 1] = (double)s_notpd;
         }
+        if (at.mirror_dst)
+            for (int i = threadIdx.x; i < at.mirror_n; i += 256) at.mirror_dst[i] = at.mirror_src[i];
         return;
     }
     long idx = (long)(blockIdx.x - 1) * 256 + threadIdx.x;
@@ -2230,7 +2292,7 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
 // dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
 // granted for (kernel slot, current device)
 static bool lds_needs_optin(int kernel_slot, size_t lds) {
-    static size_t granted[3][64] = {};
+    static size_t granted[4][64] = {};
     if (lds <= 48 * 1024) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
@@ -2258,64 +2320,89 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 // partition_tail: what both partition kernels (nearest centre, split tree) end with.  One workgroup = one chunk of
 // 256 consecutive points.  Besides the new block of its point each thread leaves
 //   rank[p]       = points of the same block earlier in the chunk,
-//   cnt[chunk][b] = points of block b in the chunk (written by the block's last point of the chunk; zeroed before),
-// from which k_unit_scan / k_place derive every table — the points of a block keep ascending index order, exactly
-// `all_idxs[blocks == i]` (block_clustering.py:21-24).  A point that changes block raises ctl[CTL_CHANGED].
+//   cnt[chunk][b] = points of block b in the chunk (written by the block's last point of the chunk; the workgroup
+//                   zeroes its own row first),
+// from which k_blk_scan / k_unit_scan / k_scatter_x derive every table — the points of a block keep ascending index
+// order, exactly `all_idxs[blocks == i]` (block_clustering.py:21-24).  A point that changes block stamps
+// ctl[CTL_CHANGED] with this evaluation's epoch (no reset needed between evaluations).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void partition_tail(int p, int n, int best, const BuildTab &bt, int *keys /* LDS [256] */) {
+__device__ __forceinline__ void partition_tail(int p, int n, int best, const BuildTab &bt, int epoch,
+                                               int *keys /* LDS [256], 16-byte aligned */) {
     int t = threadIdx.x;
+    int *row = bt.cnt + (size_t)blockIdx.x * bt.n_blocks;
+    for (int b = t; b < bt.n_blocks; b += 256) row[b] = 0;
     keys[t] = p < n ? best : -1;
     __syncthreads();
     if (p >= n) return;
     int before = 0, total = 0;
-    for (int q = 0; q < 256; ++q) {
-        int same = keys[q] == best ? 1 : 0;      // (wave-uniform address: LDS broadcast)
-        total += same;
-        before += (q < t) ? same : 0;
+    const int4 *k4 = reinterpret_cast<const int4 *>(keys);
+#pragma unroll 8
+    for (int q4 = 0; q4 < 64; ++q4) {
+        int4 k = k4[q4];                           // wave-uniform address: LDS broadcast
+        int q = 4 * q4;
+        int s0 = k.x == best, s1 = k.y == best, s2 = k.z == best, s3 = k.w == best;
+        total += s0 + s1 + s2 + s3;
+        before += (q < t ? s0 : 0) + (q + 1 < t ? s1 : 0) + (q + 2 < t ? s2 : 0) + (q + 3 < t ? s3 : 0);
     }
     bt.rank[p] = before;
-    if (before == total - 1) bt.cnt[(size_t)blockIdx.x * bt.n_blocks + best] = total;
+    if (before == total - 1) row[best] = total;
     if (bt.assign[p] != best) {
         bt.assign[p] = best;
-        bt.ctl[CTL_CHANGED] = 1;            // benign race: every writer stores the same value
+        bt.ctl[CTL_CHANGED] = epoch;        // benign race: every writer stores the same value
     }
 }
 
 // k_assign: nearest cluster centre of every point (block_clustering.py:4-5,15-17), one thread per point, the centres
-// (structure of arrays + squared norms) read wave-uniformly.  Same arithmetic as the host helper gprf_nearest_center
-// — radicand x2 - 2 x.c + c2 accumulated in the same order with no FMA contraction, a negative radicand (NaN distance)
-// wins first, otherwise the first minimum — so the two agree bit for bit.
-__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, int dx, const double *__restrict__ cs,
-                                                const double *__restrict__ c2, int nc, BuildTab bt) {
-    __shared__ int keys[256];
+// (structure of arrays + squared norms) staged through LDS a tile at a time.  Same arithmetic as the host helper
+// gprf_nearest_center — radicand x2 - 2 x.c + c2 accumulated in the same order with no FMA contraction; numpy's argmin
+// over sqrt(radicand): the FIRST negative radicand (NaN distance) wins, otherwise the first minimum — so the two agree
+// bit for bit.
+constexpr int ASSIGN_TILE = 512;
+// (DX is a template parameter: the coordinate loops unroll and x[] stays in registers — indexed by a runtime loop it
+// would live in scratch memory.)  Xcopy: the kernel's own copy of the points in HBM for the kernels that follow (X
+// itself may be pinned host memory read over the fabric).
+template <int DX>
+__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, double *__restrict__ Xcopy,
+                                                const double *__restrict__ cs, const double *__restrict__ c2, int nc,
+                                                BuildTab bt, int epoch) {
+    __shared__ __attribute__((aligned(16))) int keys[256];
+    __shared__ double scs[DX * ASSIGN_TILE], sc2[ASSIGN_TILE];
     int n = bt.n;
     int p = blockIdx.x * 256 + threadIdx.x;
-    int best = 0;
-    if (p < n) {
-        double x[8], x2 = 0.0;
-        for (int d = 0; d < dx; ++d) {
-            x[d] = X[(size_t)p * dx + d];
-            x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
+    double x[DX], x2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        x[d] = p < n ? X[(size_t)p * DX + d] : 0.0;
+        x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
+    }
+    if (Xcopy && p < n) {
+#pragma unroll
+        for (int d = 0; d < DX; ++d) Xcopy[(size_t)p * DX + d] = x[d];
+    }
+    int best = 0, neg_k = -1;
+    double bestv = 0.0;
+    for (int k0 = 0; k0 < nc; k0 += ASSIGN_TILE) {
+        int kn = nc - k0 < ASSIGN_TILE ? nc - k0 : ASSIGN_TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < kn; e += 256) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) scs[d * ASSIGN_TILE + e] = cs[(size_t)d * nc + k0 + e];
+            sc2[e] = c2[k0 + e];
         }
-        double bestv = 0.0;
-        bool best_nan = false;
-        for (int k = 0; k < nc && !best_nan; ++k) {
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < kn; ++k) {
             double r = 0.0;
-            for (int d = 0; d < dx; ++d) r = __dadd_rn(r, __dmul_rn(x[d], cs[(size_t)d * nc + k]));
-            double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2[k]);
-            if (k == 0) {
-                bestv = v;
-                best_nan = v < 0.0;
-            } else if (v < 0.0) {
-                best = k;
-                best_nan = true;
-            } else if (v < bestv) {
-                best = k;
-                bestv = v;
-            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) r = __dadd_rn(r, __dmul_rn(x[d], scs[d * ASSIGN_TILE + k]));
+            double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), sc2[k]);
+            if (k0 + k == 0) bestv = v;
+            if (v < 0.0 && neg_k < 0) neg_k = k0 + k;
+            if (v < bestv) { best = k0 + k; bestv = v; }
         }
     }
-    partition_tail(p, n, best, bt, keys);
+    if (neg_k >= 0) best = neg_k;
+    partition_tail(p, n, best, bt, epoch, keys);
 }
 
 // k_route: the seismic driver's re-blocking (pdtree_clustering.py:65-94 via gprf.py:171-172): every point descends
@@ -2323,18 +2410,23 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, in
 // longitude first moved to [-22, 338) like the reference's `(lon + 22) % 360 - 22`.  The projection is accumulated
 // column by column with separately rounded multiplies and adds, which is how gprf_amd/seismic.py builds and routes
 // (numpy element-wise ops): bit-identical decisions, including the median point whose projection equals the split.
-__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, int dx, int dim, int lon_wrap,
-                                               const double *__restrict__ vec, const double *__restrict__ center,
-                                               const double *__restrict__ split, const int32_t *__restrict__ left,
-                                               const int32_t *__restrict__ right, const int32_t *__restrict__ leaf_block,
-                                               BuildTab bt) {
-    __shared__ int keys[256];
+__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, double *__restrict__ Xcopy, int dx, int dim,
+                                               int lon_wrap, const double *__restrict__ vec,
+                                               const double *__restrict__ center, const double *__restrict__ split,
+                                               const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                                               const int32_t *__restrict__ leaf_block, BuildTab bt, int epoch) {
+    __shared__ __attribute__((aligned(16))) int keys[256];
     int n = bt.n;
     int p = blockIdx.x * 256 + threadIdx.x;
     int best = 0;
     if (p < n) {
-        double x[8];
-        for (int d = 0; d < dim; ++d) x[d] = X[(size_t)p * dx + d];
+        double x[3] = {0.0, 0.0, 0.0};              // dx <= 3 (gprf_create); fixed-bound loops keep x[] in registers
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < dx) {
+                x[d] = X[(size_t)p * dx + d];
+                if (Xcopy) Xcopy[(size_t)p * dx + d] = x[d];
+            }
         if (lon_wrap) {
             double r = fmod(__dadd_rn(x[0], 22.0), 360.0);          // numpy's %: the result takes the divisor's sign
             if (r != 0.0) { if (r < 0.0) r = __dadd_rn(r, 360.0); } else r = 0.0;
@@ -2343,41 +2435,52 @@ __global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, int
         int k = 0;
         while (left[k] >= 0) {
             double a = __dmul_rn(__dsub_rn(x[0], center[(size_t)k * dim]), vec[(size_t)k * dim]);
-            for (int d = 1; d < dim; ++d)
-                a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
+#pragma unroll
+            for (int d = 1; d < 3; ++d)
+                if (d < dim)
+                    a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
             k = (a < split[k]) ? left[k] : right[k];
         }
         best = leaf_block[k];
     }
-    partition_tail(p, n, best, bt, keys);
+    partition_tail(p, n, best, bt, epoch, keys);
 }
 
-void launch_assign(const double *X, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt, hipStream_t s) {
+void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt,
+                   int epoch, hipStream_t s) {
     if (bt.n == 0) return;
-    hipLaunchKernelGGL(k_assign, dim3(bt.n_chunks), dim3(256), 0, s, X, dx, cs, c2, nc, bt);
+    dim3 g(bt.n_chunks), b(256);
+    if (dx == 1) hipLaunchKernelGGL((k_assign<1>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
+    else if (dx == 2) hipLaunchKernelGGL((k_assign<2>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
+    else hipLaunchKernelGGL((k_assign<3>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
 }
 
-void launch_route(const double *X, int dx, int dim, int lon_wrap, const double *vec, const double *center,
+void launch_route(const double *X, double *Xcopy, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
-                  const BuildTab &bt, hipStream_t s) {
+                  const BuildTab &bt, int epoch, hipStream_t s) {
     if (bt.n == 0) return;
-    hipLaunchKernelGGL(k_route, dim3(bt.n_chunks), dim3(256), 0, s, X, dx, dim, lon_wrap, vec, center, split, left,
-                       right, leaf_block, bt);
+    hipLaunchKernelGGL(k_route, dim3(bt.n_chunks), dim3(256), 0, s, X, Xcopy, dx, dim, lon_wrap, vec, center, split, left,
+                       right, leaf_block, bt, epoch);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_unit_scan (ONE workgroup): the unit tables from the partition.
-//   (a) from_chunks: per block, the exclusive prefix of cnt over the chunks (in place) and the block size;
-//   (b) per local unit: m = |block i| (+ |block j|), off_j = |block i|, and the running offsets row_off = sum mp,
-//       mat_off = sum mp^2 (mp = m rounded up to 16) — what rebuild_units did on the host (gprf.py:236-239 order);
-//   (c) the totals, checked against the workspace the host reserved and the max_T the evaluation's kernels will be
-//       launched with: on overflow every unit gets m = 0 (each kernel then has nothing to do) and ctl says so; the
-//       host grows the workspace and repeats the evaluation.
-// ------------------------------------------------------------------------------------------------
-constexpr int SCAN_THREADS = 1024;
+// whether this evaluation rebuilds the tables: asked to (force), or the partition kernel stamped a change
+__device__ __forceinline__ bool rebuilding(const BuildTab &bt, int force, int epoch) {
+    return force || bt.ctl[CTL_CHANGED] == epoch;
+}
 
-// exclusive prefix sums of a (int64) and b (int64) over the workgroup; returns the totals through ta / tb
-__device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long *sh /* LDS [2][16] */, long long *ta,
+// k_build: the unit tables from the partition, in two launches of the same kernel.
+//  (1) from_chunks = 1: per block (one wave each, four per workgroup), the exclusive prefix of cnt over the chunks (in
+//      place) and the block size;
+//  (2) from_chunks = 0, ONE workgroup: the unit scan: per local unit m = |block i| (+ |block j|), off_j = |block i|, and the running offsets row_off = sum mp,
+//      mat_off = sum mp^2 (mp = m rounded up to 16) — what rebuild_units did on the host (gprf.py:236-239 order); the
+//      unit's padding rows of the coordinate pool are zeroed; the totals are checked against the workspace the host
+//      reserved and the max_T the evaluation's kernels will be launched with: on overflow every unit gets m = 0 (each
+//      kernel then has nothing to do) and ctl says so; the host grows the workspace and repeats the evaluation.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+
+// exclusive prefix sums of a and b over the workgroup; returns the totals through ta / tb
+__device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long *sh /* LDS [2][4] */, long long *ta,
                                            long long *tb) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long ia = a, ib = b;
@@ -2385,12 +2488,12 @@ __device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long
         long long ua = __shfl_up(ia, off, 64), ub = __shfl_up(ib, off, 64);
         if (lane >= off) { ia += ua; ib += ub; }
     }
-    if (lane == 63) { sh[wave] = ia; sh[16 + wave] = ib; }
+    if (lane == 63) { sh[wave] = ia; sh[4 + wave] = ib; }
     __syncthreads();
     long long pa = 0, pb = 0, sa = 0, sb = 0;
     for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-        if (w < wave) { pa += sh[w]; pb += sh[16 + w]; }
-        sa += sh[w]; sb += sh[16 + w];
+        if (w < wave) { pa += sh[w]; pb += sh[4 + w]; }
+        sa += sh[w]; sb += sh[4 + w];
     }
     __syncthreads();
     a = pa + ia - a;
@@ -2399,25 +2502,32 @@ __device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long
     *tb = sb;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_unit_scan(BuildTab bt, int from_chunks, int force) {
-    __shared__ long long sh[32];
+__global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_chunks, int force, int epoch) {
+    __shared__ long long sh[8];
     __shared__ int s_maxm;
-    if (!force && !bt.ctl[CTL_CHANGED]) return;
-    int t = threadIdx.x;
-    if (t == 0) s_maxm = 0;
+    if (!rebuilding(bt, force, epoch)) return;
+    int t = threadIdx.x, lane = t & 63;
     if (from_chunks) {
-        for (int b = t; b < bt.n_blocks; b += SCAN_THREADS) {
+        int b = blockIdx.x * 4 + (t >> 6);
+        if (b < bt.n_blocks) {
             int run = 0;
-            for (int c = 0; c < bt.n_chunks; ++c) {
+            for (int c0 = 0; c0 < bt.n_chunks; c0 += 64) {
+                int c = c0 + lane;
                 int *e = bt.cnt + (size_t)c * bt.n_blocks + b;
-                int v = *e;
-                *e = run;
-                run += v;
+                int v = c < bt.n_chunks ? *e : 0;
+                int inc = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    int u = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += u;
+                }
+                if (c < bt.n_chunks) *e = run + inc - v;
+                run += __shfl(inc, 63, 64);
             }
-            bt.bsize[b] = run;
+            if (lane == 0) bt.bsize[b] = run;
         }
+        return;
     }
-    __threadfence_block();
+    if (t == 0) s_maxm = 0;
     __syncthreads();
     long long rows = 0, mat = 0;
     for (int l0 = 0; l0 < bt.n_local; l0 += SCAN_THREADS) {
@@ -2445,10 +2555,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unit_scan(BuildTab bt, int fro
     int maxm = s_maxm;
     int maxT = ((maxm + 15) & ~15) >> 4;
     bool over = rows > bt.cap_rows || mat > bt.cap_mat || maxT > bt.maxT_bound || maxm > MAX_MP;
-    if (over)
-        for (int l = t; l < bt.n_local; l += SCAN_THREADS) { bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0; }
+    // the Cholesky's two launch lists (units of more than small_maxT tiles one to a CU, the others two to a CU): a
+    // stable partition of the launch order by THIS partition's sizes
+    long long nbig = 0;
+    if (bt.small_maxT > 0) {
+        for (int k0 = 0; k0 < bt.n_local; k0 += SCAN_THREADS) {
+            int k = k0 + t;
+            int u = 0;
+            long long big = 0, one = 0, tb_, to_;
+            if (k < bt.n_local) {
+                u = bt.ids[k];
+                big = ((bt.m[u] + 15) >> 4) > bt.small_maxT ? 1 : 0;
+                one = 1;
+            }
+            long long isbig = big, pos = one;
+            wg_exscan2(big, pos, sh, &tb_, &to_);
+            if (k < bt.n_local) {
+                if (isbig) bt.big_list[nbig + big] = u;
+                else bt.small_list[(k0 - nbig) + (pos - big)] = u;
+            }
+            nbig += tb_;
+        }
+        over = over || nbig > bt.grid_big || (bt.n_local - nbig) > bt.grid_small;
+    }
+    for (int l = t; l < bt.n_local; l += SCAN_THREADS) {
+        if (over) {
+            bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0;
+        } else {
+            // the unit's padding rows of the coordinate pool: zero (k_scatter_x writes the rows below m only)
+            int m = bt.m[l], mp = (m + 15) & ~15;
+            double *xr = bt.Xu + (size_t)(bt.row_off[l] + m) * bt.xstride;
+            for (int e = 0; e < (mp - m) * bt.xstride; ++e) xr[e] = 0.0;
+        }
+    }
     if (t == 0) {
         bt.ctl[CTL_OVERFLOW] = over ? 1 : 0;
+        bt.ctl[CTL_NBIG] = over ? 0 : (int32_t)nbig;
+        bt.ctl[CTL_NSMALL] = over ? 0 : (int32_t)(bt.n_local - nbig);
         bt.ctl[CTL_ROWS] = (int32_t)rows;
         bt.ctl[CTL_MAXT] = maxT;
         bt.ctl[CTL_MAXM] = maxm;
@@ -2458,38 +2601,65 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unit_scan(BuildTab bt, int fro
     }
 }
 
-// k_place: position of every point inside its block and its rows in the unit row -> point table: the point sits at
-// position posb of its block in every local unit that contains the block (rows of block j after block i's,
-// gprf.py:322-326).
-__global__ __launch_bounds__(256) void k_place(BuildTab bt, int from_chunks, int force) {
-    if (!force && !bt.ctl[CTL_CHANGED]) return;
+// k_scatter_x (every evaluation): a point's coordinate record into its row of every local unit that contains its
+// block — position posb of the block, rows of block j after block i's (gprf.py:322-326) — and, when the tables are
+// being rebuilt, the position itself (from the chunk ranks) and the unit row -> point table.
+__global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__restrict__ X, int dx, int geo,
+                                                   int from_chunks, int force, int epoch) {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= bt.n) return;
     int b = bt.assign[p];
     if (b < 0) return;
+    bool rebuild = rebuilding(bt, force, epoch);
     int pos;
-    if (from_chunks) {
+    if (rebuild && from_chunks) {
         pos = bt.cnt[(size_t)blockIdx.x * bt.n_blocks + b] + bt.rank[p];
         bt.posb[p] = pos;
     } else {
         pos = bt.posb[p];
     }
     if (bt.ctl[CTL_OVERFLOW]) return;
+    double r0, r1, r2, r3, r4 = 0.0;
+    if (geo) {
+        // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
+        double lon = X[(size_t)p * dx], lat = X[(size_t)p * dx + 1], z = X[(size_t)p * dx + 2];
+        double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
+        r0 = sin(hl); r1 = cos(hl); r2 = sin(hn); r3 = cos(hn); r4 = z;      // GEO_SLH, GEO_CLH, GEO_SNH, GEO_CNH, GEO_Z
+    } else {
+        r0 = X[(size_t)p * dx];
+        r1 = dx > 1 ? X[(size_t)p * dx + 1] : 0.0;
+        r2 = dx > 2 ? X[(size_t)p * dx + 2] : 0.0;
+        r3 = 0.0;
+    }
+    typedef double d2v __attribute__((ext_vector_type(2)));
     for (int e = bt.bu_ptr[b]; e < bt.bu_ptr[b + 1]; ++e) {
         int ent = bt.bu_ent[e];
         int u = ent >> 1;
-        bt.upt[bt.row_off[u] + ((ent & 1) ? bt.off_j[u] : 0) + pos] = p;
+        int row = bt.row_off[u] + ((ent & 1) ? bt.off_j[u] : 0) + pos;
+        if (rebuild) bt.upt[row] = p;
+        d2v *dst = reinterpret_cast<d2v *>(bt.Xu + (size_t)row * (geo ? GEO_STRIDE : XPAD));      // 32- / 64-byte rows
+        dst[0] = d2v{r0, r1};
+        dst[1] = d2v{r2, r3};
+        if (geo) {
+            dst[2] = d2v{r4, 0.0};
+            dst[3] = d2v{0.0, 0.0};
+        }
     }
 }
 
-void launch_build_tables(const BuildTab &bt, int from_chunks, int force, hipStream_t s) {
-    hipLaunchKernelGGL(k_unit_scan, dim3(1), dim3(SCAN_THREADS), 0, s, bt, from_chunks, force);
-    if (bt.n > 0) hipLaunchKernelGGL(k_place, dim3(bt.n_chunks), dim3(256), 0, s, bt, from_chunks, force);
+void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epoch, hipStream_t s) {
+    // (two launches: merged into one with an arrival ticket they took 19.8 us against 4.9 + 13.3 — the unit scan is a
+    // chain of dependent memory round trips either way)
+    if (from_chunks && bt.n_blocks > 0)
+        hipLaunchKernelGGL(k_build, dim3((bt.n_blocks + 3) / 4), dim3(SCAN_THREADS), 0, s, bt, 1, force, epoch);
+    hipLaunchKernelGGL(k_build, dim3(1), dim3(SCAN_THREADS), 0, s, bt, 0, force, epoch);
 }
 
-void launch_gather_x(int dist_id, const UnitTab &ut, const Pools &p, const double *X, int dx, hipStream_t s) {
-    if (ut.n_units == 0) return;
-    hipLaunchKernelGGL(k_gather_x, dim3(ut.n_units), dim3(256), 0, s, ut, X, p.Xu, dx, dist_id == 1 ? 1 : 0);
+void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, int from_chunks, int force, int epoch,
+                      hipStream_t s) {
+    if (bt.n == 0) return;
+    hipLaunchKernelGGL(k_scatter_x, dim3(bt.n_chunks), dim3(256), 0, s, bt, X, dx, dist_id == 1 ? 1 : 0, from_chunks,
+                       force, epoch);
 }
 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
@@ -2516,7 +2686,16 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     return !off && dist_id == 0 && kern_id == 0 && ut.n_ids > 0 && ut.max_T <= POTRF_REG_MAXT_C && potrf_use_reg(ut);
 }
 
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s) {
+constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
+constexpr int POTRF_SMALL_MAXT = 13;
+bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation only (diagnostics)
+    static const bool on = [] { const char *e = getenv("GPRF_POTRF_DUAL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
+
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, hipStream_t s2,
+                  hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (ut.n_ids == 0) return;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
     int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
@@ -2531,11 +2710,53 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
         if (gen && ut.max_T <= reg_maxT) {
             lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
+            static const bool serial = [] { const char *e = getenv("GPRF_POTRF_DUAL"); return e && e[0] == '2'; }();
+            if (serial) s2 = s;      // diagnostic: the two instantiations one after the other (standalone durations)
+            const bool dual = potrf_dual_enabled();
+            if (dual && s2 && ut.max_T > POTRF_SMALL_MAXT) {
+                // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
+                // larger ones one to a CU; each skips the other's units
+                int capS = POTRF_SMALL_MAXT;
+                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
+                if (lds_needs_optin(3, ldsS))
+                    (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
+                if (lds_needs_optin(2, lds))
+                    (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (s2 != s) {
+                    (void)hipEventRecord(ev_fork, s);
+                    (void)hipStreamWaitEvent(s2, ev_fork, 0);
+                }
+                // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
+                // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
+                // the grids follow the list lengths of the last synchronised partition with a little slack)
+                if (ut.grid_big > 0)
+                    hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
+                                       dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 1);
+                if (ut.grid_small > 0)
+                    hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.grid_small),
+                                       dim3(POTRF_REG_WAVES * 64), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
+                if (s2 != s) {
+                    (void)hipEventRecord(ev_join, s2);
+                    (void)hipStreamWaitEvent(s, ev_join, 0);
+                }
+                return;
+            }
+            if (ut.max_T <= POTRF_SMALL_MAXT && dual) {
+                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
+                if (lds_needs_optin(3, ldsS))
+                    (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
+                hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.n_ids),
+                                   dim3(POTRF_REG_WAVES * 64), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
+                return;
+            }
             if (lds_needs_optin(2, lds))
                 (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.n_ids),
-                               dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp);
+                               dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 0);
             return;
         }
         if (lds_needs_optin(0, lds))
@@ -2543,7 +2764,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
                            ut, p,
-                           stamps, reg_maxT, kp);
+                           stamps, reg_maxT, kp, 0);
         if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
     }
     size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
@@ -2605,6 +2826,17 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
         hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
     }
 }
+
+// k_done: the last kernel of a host-in / host-out evaluation: everything before it on the stream has completed
+// (kernel boundary), so one store of the evaluation's sequence number into pinned host memory tells a polling host
+// that the result is there — a few microseconds instead of the runtime's stream-synchronisation path.
+__global__ void k_done(int32_t *flag, int32_t seq) {
+    if (threadIdx.x == 0) {
+        __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+    }
+}
+
+void launch_done(int32_t *flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_done, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s) {

@@ -19,7 +19,7 @@ def short(name):
     if "k_mgrad" in name and ("<0, 0, true>" in name or "ILi0ELi0ELb1E" in name):
         return "k_mgrad_readK"
     for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
-              "k_gather_x", "k_gather_y"):
+              "k_gather_x", "k_assign", "k_route", "k_unit_scan", "k_place"):
         if k in name:
             return k
     return name[:40]

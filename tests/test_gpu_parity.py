@@ -494,19 +494,14 @@ def test_reblocking_that_outgrows_the_workspace_is_repeated():
     fresh = GPRF(X2, Y, None, cov, 0.01, block_idxs=b.block_clusters(X2), neighbors=b.neighbors())
     c = fresh.llgrad(grad_X=True, grad_cov=True)
     assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
-    # and back again: THIS evaluation still runs under the large launch bound (other kernel instantiations than a fresh
-    # context picks: equal to rounding, not to the bit); the bound has followed by the next one
+    # and back again: the evaluation still runs under the large launch bound (other kernel instantiations than a fresh
+    # context picks: equal to rounding, not to the bit); the bound follows down after a run of smaller partitions
     g.update_X(X)
     a = g.llgrad(grad_X=True)
     fresh.close()
     fresh = GPRF(X, Y, None, cov, 0.01, block_idxs=b.block_clusters(X), neighbors=b.neighbors())
     c = fresh.llgrad(grad_X=True)
     assert np.isclose(a[0], c[0], rtol=1e-13) and _close(a[1], c[1], 1e-12)
-    g.update_X(X + 1e-12)
-    a = g.llgrad(grad_X=True)
-    fresh.update_X(X + 1e-12)
-    c = fresh.llgrad(grad_X=True)
-    assert a[0] == c[0] and np.array_equal(a[1], c[1])
     g.close(); fresh.close()
 
 
@@ -530,4 +525,49 @@ def test_set_blocks_refuses_a_point_listed_twice():
     r = GPRFRef(X, Y, None, OC([1.0], [0.3, 0.3], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=[(1, 0)])
     o = r.llgrad(grad_X=True)
     assert np.isclose(ll, o[0], rtol=1e-12) and _close(gX, o[1], 1e-10)
+    g.close()
+
+
+def test_cholesky_launch_lists_follow_the_partition():
+    """The register-resident Cholesky runs as two instantiations side by side: units of up to 13 tiles per edge (208
+    points) two to a CU, larger ones one to a CU, each over its own list, which k_build re-derives ON THE DEVICE from the
+    sizes of every new partition (the host only sizes the two launches, from the last synchronised lengths + slack; a
+    list that outgrows its launch makes the evaluation repeat with larger ones).  Partitions that move units between
+    the classes — a few, then many at once — give the numbers of a fresh context on that partition, bit for bit."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(41)
+    n = 6000
+    X = rng.rand(n, 2)
+    Y = rng.randn(n, 5)
+    b = Blocker(grid_centers(64))
+    cov = GPCov([1.0], [0.06, 0.06], "euclidean", "se")
+    nb = b.neighbors()
+    g = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nb)
+    g.llgrad(grad_X=True)
+
+    def classes(Xk):
+        sz = np.array([len(v) for v in b.block_clusters(Xk)])
+        ps = np.array([sz[i] + sz[j] for (i, j) in nb])
+        assert ps.max() <= 256
+        return int((ps > 208).sum()), int((ps <= 208).sum())
+
+    big0, small0 = classes(X)
+    assert 0 < big0 < 30 and small0 > 0
+    # (1) a jitter that moves a handful of units across the 208-point line; (2) 500 points re-drawn from the border
+    # blocks into the interior: dozens of pairs enter the large class at once (more than the launch slack)
+    X1 = X + 0.004 * rng.randn(n, 2)
+    r2 = np.random.RandomState(5)
+    mv = r2.choice(np.where(np.abs(X - 0.5).max(axis=1) > 0.375)[0], 500, replace=False)
+    X2 = X.copy()
+    X2[mv] = 0.125 + 0.75 * r2.rand(500, 2)
+    big2, _ = classes(X2)
+    assert big2 > big0 + 40
+    for Xk in (X1, X2, X):
+        g.update_X(Xk)
+        a = g.llgrad(grad_X=True, grad_cov=True)
+        fresh = GPRF(Xk, Y, None, cov, 0.01, block_idxs=b.block_clusters(Xk), neighbors=nb)
+        c = fresh.llgrad(grad_X=True, grad_cov=True)
+        assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+        fresh.close()
     g.close()
