@@ -1480,9 +1480,17 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     const double *__restrict__ V = pl.V + roff * 16;
     double *__restrict__ W = pl.W + ut.mat_off[u];
     double *__restrict__ Z = pl.Z + roff * YPAD;
-    const int32_t *__restrict__ upt = ut.upt + roff;
     const double *__restrict__ Yg = pl.Y;
     int r0 = is_y ? 0 : cb;
+    // the Y workgroup gathers its right-hand side through the unit row -> point table: the table goes through LDS
+    // first (one coalesced load), so that the gather itself is a single round of independent loads
+    // (in the second panel buffer, which the step loop writes only after its first barrier: the two panels + V already
+    // fill half of the CU's LDS exactly, and one more kilobyte would halve the occupancy)
+    int32_t *s_upt = reinterpret_cast<int32_t *>(&panel[1][0]);
+    if (is_y) {
+        for (int e = tid; e < mp; e += 256) s_upt[e] = e < m ? ut.upt[roff + e] : -1;
+        __syncthreads();
+    }
 
     // (static_for, not "#pragma unroll": the optimizer gives up on the 28-tile instantiation's loops and the
     // accumulators would land in scratch)
@@ -1495,7 +1503,8 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
             if (live && r >= r0 && r < T) {
                 if (is_y) {
                     int row = 16 * r + lg + 4 * q, col = 16 * cb + lr;     // Y[unit rows]: gathered here, zero padded
-                    if (row < m && col < dy) v = Yg[(size_t)upt[row] * dy + col];
+                    int pt = s_upt[row];
+                    if (pt >= 0 && col < dy) v = Yg[(size_t)pt * dy + col];
                 } else {
                     v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
                 }
