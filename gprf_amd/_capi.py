@@ -31,6 +31,7 @@ SIGNATURES = {
     "gprf_set_theta": (ctypes.c_int, [_vp, _dp, _i32]),
     "gprf_set_blocks": (ctypes.c_int, [_vp, _i32, _i64p, _i32p]),
     "gprf_set_neighbors": (ctypes.c_int, [_vp, _i32, _i32p]),
+    "gprf_pair_kernel_max": (ctypes.c_int, [_vp, _dp, _i32, _i64p, _i32p, ctypes.c_double, _i32, _i32p, _i32p, _dp]),
     "gprf_nearest_center": (ctypes.c_int, [_i32, _i32, _dp, _i32, _dp, _i32p]),
     "gprf_set_block_assignment": (ctypes.c_int, [_vp, _i32, _i32p]),
     "gprf_set_centers": (ctypes.c_int, [_vp, _i32, _dp]),
@@ -219,6 +220,20 @@ class Context(object):
         self._check(self.lib.gprf_assign_blocks(self.h, dptr(X), ctypes.byref(changed), out.ctypes.data_as(_i32p)),
                     "gprf_assign_blocks")
         return (True, out) if changed.value else (False, None)
+
+    def pair_kernel_max(self, X, block_ptr, point_idx, threshold, cand, want_max=False):
+        """-> keep flags (and the exact maxima if ``want_max``) for the candidate block pairs (gprf.py:119-150)"""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        block_ptr = np.ascontiguousarray(block_ptr, dtype=np.int64)
+        point_idx = np.ascontiguousarray(point_idx, dtype=np.int32)
+        cand = np.ascontiguousarray(np.asarray(cand, dtype=np.int32).reshape(-1, 2))
+        keep = np.zeros(len(cand), dtype=np.int32)
+        mx = np.zeros(len(cand)) if want_max else None
+        self._check(self.lib.gprf_pair_kernel_max(self.h, dptr(X), len(block_ptr) - 1, block_ptr.ctypes.data_as(_i64p),
+                                                  point_idx.ctypes.data_as(_i32p), float(threshold), len(cand),
+                                                  cand.ctypes.data_as(_i32p), keep.ctypes.data_as(_i32p),
+                                                  dptr(mx) if want_max else None), "gprf_pair_kernel_max")
+        return (keep, mx) if want_max else keep
 
     def set_neighbors(self, pairs):
         pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))

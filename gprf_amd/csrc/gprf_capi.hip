@@ -1067,6 +1067,49 @@ int gprf_get_block_assignment(gprf_ctx *c, int32_t *block_of_out) {
     return fetch_assignment(c, block_of_out);
 }
 
+int gprf_pair_kernel_max(gprf_ctx *c, const double *X, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx,
+                         double threshold, int32_t n_cand, const int32_t *cand_ij, int32_t *keep_out, double *max_out) {
+    if (!c || !X || n_blocks < 0 || !block_ptr || n_cand < 0 || (n_cand > 0 && (!cand_ij || !keep_out))) return GPRF_ERR_ARG;
+    if (!c->have_theta) return fail(c, GPRF_ERR_STATE, "gprf_set_theta has not been called");
+    if (n_cand == 0) return GPRF_OK;
+    int64_t tot = block_ptr[n_blocks];
+    if (tot > 0 && !point_idx) return GPRF_ERR_ARG;
+    for (int64_t k = 0; k < tot; ++k)
+        if (point_idx[k] < 0 || point_idx[k] >= c->n) return fail(c, GPRF_ERR_ARG, "point index out of range");
+    for (int q = 0; q < 2 * n_cand; ++q)
+        if (cand_ij[q] < 0 || cand_ij[q] >= n_blocks) return fail(c, GPRF_ERR_ARG, "candidate pair refers to a block out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // one-time setup work (the reference caches its result in a file, run_seismic.py:377-404): plain allocations
+    DevBuf<double> dX, dmax;
+    DevBuf<int64_t> dptr;
+    DevBuf<int32_t> dpts, dcand, dkeep;
+    auto cleanup = [&]() { dX.release(); dmax.release(); dptr.release(); dpts.release(); dcand.release(); dkeep.release(); };
+    size_t nx = (size_t)c->n * c->dx;
+    hipError_t e = hipSuccess;
+    if ((e = dX.reserve(nx + 1, 1.0)) != hipSuccess || (e = dptr.reserve((size_t)n_blocks + 1, 1.0)) != hipSuccess ||
+        (e = dpts.reserve((size_t)tot + 1, 1.0)) != hipSuccess || (e = dcand.reserve(2 * (size_t)n_cand, 1.0)) != hipSuccess ||
+        (e = dkeep.reserve((size_t)n_cand, 1.0)) != hipSuccess || (max_out && (e = dmax.reserve((size_t)n_cand, 1.0)) != hipSuccess)) {
+        cleanup();
+        return fail(c, GPRF_ERR_HIP, std::string("gprf_pair_kernel_max: ") + hipGetErrorString(e));
+    }
+    hipStream_t s = c->stream;
+    bool ok = hipMemcpyAsync(dX.p, X, nx * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dptr.p, block_ptr, ((size_t)n_blocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s) == hipSuccess &&
+              (tot == 0 || hipMemcpyAsync(dpts.p, point_idx, (size_t)tot * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess) &&
+              hipMemcpyAsync(dcand.p, cand_ij, 2 * (size_t)n_cand * sizeof(int32_t), hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemsetAsync(dkeep.p, 0, (size_t)n_cand * sizeof(int32_t), s) == hipSuccess;
+    if (ok) {
+        launch_pair_max(c->dist_id, c->kern_id, dX.p, c->dx, dptr.p, dpts.p, dcand.p, n_cand, make_kparams(c), threshold,
+                        max_out ? 1 : 0, dkeep.p, max_out ? dmax.p : nullptr, s);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(keep_out, dkeep.p, (size_t)n_cand * sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             (!max_out || hipMemcpyAsync(max_out, dmax.p, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess) &&
+             hipStreamSynchronize(s) == hipSuccess;
+    }
+    cleanup();
+    return ok ? GPRF_OK : fail(c, GPRF_ERR_HIP, "gprf_pair_kernel_max: HIP error");
+}
+
 int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
     if (!c || n_pairs < 0 || (n_pairs > 0 && !pairs_ij)) return GPRF_ERR_ARG;
     c->n_pairs = n_pairs;

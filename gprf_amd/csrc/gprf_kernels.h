@@ -148,5 +148,9 @@ void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s);
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s);
+// threshold neighbour discovery: keep[c] = max |k| / sv over candidate block pair c > thr (early out unless want_max)
+void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const int64_t *blk_ptr, const int32_t *blk_pts,
+                     const int32_t *cand, int n_cand, const KParams &kp, double thr, int want_max, int32_t *keep,
+                     double *max_out, hipStream_t s);
 
 }  // namespace gprf

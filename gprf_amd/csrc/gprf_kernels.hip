@@ -2836,6 +2836,99 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pair_max: threshold neighbour discovery (gprf.py:119-150): for a candidate block pair (i, j) the largest
+// |k(x_p, x_q)| / signal_var over p in block i, q in block j — one workgroup per candidate, 64 x 64 point tiles (the
+// coordinates / great-circle records of the tile's points wait in LDS), the pair is decided as soon as one tile holds
+// a value above the threshold (want_max = 0), exactly the reference's `np.max(np.abs(K / wfn_var)) > threshold`.
+// ------------------------------------------------------------------------------------------------
+template <int DIST, int KERN>
+__global__ __launch_bounds__(256) void k_pair_max(const double *__restrict__ X, int dx, const int64_t *__restrict__ blk_ptr,
+                                                  const int32_t *__restrict__ blk_pts, const int32_t *__restrict__ cand,
+                                                  KParams kp, double thr, int want_max, int32_t *__restrict__ keep,
+                                                  double *__restrict__ max_out) {
+    constexpr int XN = PtRec<DIST>::NREG;
+    __shared__ double xi[64][XN], xj[64][XN];
+    __shared__ double wred[4];
+    int c = blockIdx.x;
+    int bi = cand[2 * c], bj = cand[2 * c + 1];
+    int64_t i0 = blk_ptr[bi], i1 = blk_ptr[bi + 1], j0 = blk_ptr[bj], j1 = blk_ptr[bj + 1];
+    int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto load = [&](double (*dst)[XN], int64_t p0, int64_t p1) {
+        if (t < 64) {
+            int64_t k = p0 + t;
+            double r[XN];
+#pragma unroll
+            for (int d = 0; d < XN; ++d) r[d] = 0.0;
+            if (k < p1) {
+                const double *x = X + (size_t)blk_pts[k] * dx;
+                if constexpr (DIST == 1) {
+                    double hl = x[1] * DEG2RAD / 2.0, hn = x[0] * DEG2RAD / 2.0;
+                    r[GEO_SLH] = sin(hl); r[GEO_CLH] = cos(hl); r[GEO_SNH] = sin(hn); r[GEO_CNH] = cos(hn); r[GEO_Z] = x[2];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) if (d < dx) r[d] = x[d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < XN; ++d) dst[t][d] = r[d];
+        }
+    };
+    double best = 0.0;
+    const double inv_sv = 1.0 / kp.sv;
+    for (int64_t a = i0; a < i1; a += 64) {
+        __syncthreads();
+        load(xi, a, i1);
+        for (int64_t b = j0; b < j1; b += 64) {
+            __syncthreads();
+            load(xj, b, j1);
+            __syncthreads();
+            double m = 0.0;
+            if (b + lane < j1) {
+                double xq[XN];
+#pragma unroll
+                for (int d = 0; d < XN; ++d) xq[d] = xj[lane][d];
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    int r = wave + 4 * q;
+                    if (a + r < i1) {
+                        double v = fabs(KernFn<DIST, KERN>::value(kp, xi[r], xq) / kp.sv);      // |K / wfn_var| (gprf.py:141)
+                        m = v > m ? v : m;
+                    }
+                }
+            }
+            (void)inv_sv;
+            best = m > best ? m : best;
+            if (!want_max && __syncthreads_or(m > thr)) {
+                if (t == 0) keep[c] = 1;
+                return;
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        double o = shfl_xor_d(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) wred[wave] = best;
+    __syncthreads();
+    if (t == 0) {
+        double mx = wred[0];
+        for (int w = 1; w < 4; ++w) mx = wred[w] > mx ? wred[w] : mx;
+        keep[c] = mx > thr ? 1 : 0;
+        if (max_out) max_out[c] = mx;
+    }
+}
+
+void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const int64_t *blk_ptr, const int32_t *blk_pts,
+                     const int32_t *cand, int n_cand, const KParams &kp, double thr, int want_max, int32_t *keep,
+                     double *max_out, hipStream_t s) {
+    if (n_cand == 0) return;
+    if (dist_id == 0 && kern_id == 0)
+        hipLaunchKernelGGL((k_pair_max<0, 0>), dim3(n_cand), dim3(256), 0, s, X, dx, blk_ptr, blk_pts, cand, kp, thr, want_max, keep, max_out);
+    else
+        hipLaunchKernelGGL((k_pair_max<1, 1>), dim3(n_cand), dim3(256), 0, s, X, dx, blk_ptr, blk_pts, cand, kp, thr, want_max, keep, max_out);
+}
+
 // k_done: the last kernel of a host-in / host-out evaluation: everything before it on the stream has completed
 // (kernel boundary), so one store of the evaluation's sequence number into pinned host memory tells a polling host
 // that the result is there — a few microseconds instead of the runtime's stream-synchronisation path.

@@ -149,10 +149,17 @@ class GPRF(object):
     # ------------------------------------------------------------------ reference surface
     def compute_neighbors(self, threshold=1e-3):
         """gprf.py:119-150: connect blocks whose largest cross-covariance (relative to the signal
-        variance) exceeds ``threshold``; 1.0 means no pairs.  One-time setup, evaluated on the host with
-        the same kernel definitions (block pairs whose bounding boxes are already too far apart are skipped)."""
-        from .hostkernels import threshold_neighbors
-        self.neighbors = threshold_neighbors(self.X, self.block_idxs, self.cov, threshold)
+        variance) exceeds ``threshold``; 1.0 means no pairs.  The host prunes the block pairs by geometry
+        (neighbors.candidate_block_pairs: no kernel evaluation), the device decides the candidates
+        (gprf_pair_kernel_max): the same list, in the same order, as the reference's exhaustive double loop."""
+        from .neighbors import candidate_block_pairs
+        cand = candidate_block_pairs(self.X, self.block_idxs, self.cov, threshold)
+        if not cand:
+            self.neighbors = []
+            return
+        ptr, pts = _csr_from_block_idxs(self.block_idxs)
+        keep = self._ctx.pair_kernel_max(self.X, ptr, pts, threshold, cand)
+        self.neighbors = [c for c, k in zip(cand, keep) if k]
 
     def compute_neighbor_count(self):
         """gprf.py:152-157"""

@@ -273,7 +273,7 @@ def synthetic_events(n, seed=0):
 
 def sample_y(X, cov, noise_var, yd, seed=0):
     """Dense draw Y = chol(k(X, X) + noise_var I) Z (the small-n branch of run_seismic.sample_y / synthetic.py:103-114)."""
-    from .hostkernels import kernel_matrix
+    from .synthetic import prior_kernel_matrix as kernel_matrix
     rng = np.random.RandomState(seed)
     K = kernel_matrix(X, X, cov) + noise_var * np.eye(len(X))
     return np.linalg.cholesky(K).dot(rng.randn(len(X), yd))

@@ -9,7 +9,31 @@ import numpy as np
 
 from .blocking import Blocker
 from .cov import GPCov
-from . import hostkernels
+from .neighbors import great_circle_km
+
+
+def prior_kernel_matrix(X1, X2, cov):
+    """The covariance the synthetic outputs are DRAWN from (treegp's ``mcov``, synthetic.py:108): noise-free k(X1, X2)
+    for ("euclidean" | "lld") x ("se" | "matern32"), plain numpy.  Part of the input recipe (what the path is fed) — the
+    GPRF objective itself is never evaluated with it."""
+    X1, X2 = np.asarray(X1, dtype=np.float64), np.asarray(X2, dtype=np.float64)
+    ls = np.asarray(cov.dfn_params, dtype=np.float64)
+    if cov.dfn_str == "euclidean":
+        diff = (X1[:, None, :] - X2[None, :, :]) / ls[None, None, :]
+        d = np.sqrt(np.sum(diff * diff, axis=2))
+    elif cov.dfn_str == "lld":
+        g = great_circle_km(X1[:, None, 0], X1[:, None, 1], X2[None, :, 0], X2[None, :, 1]) / ls[0]
+        dz = (X1[:, None, 2] - X2[None, :, 2]) / ls[1]
+        d = np.sqrt(g * g + dz * dz)
+    else:
+        raise ValueError(cov.dfn_str)
+    sv = cov.wfn_params[0]
+    if cov.wfn_str == "se":
+        return sv * np.exp(-1.0 * d * d)
+    if cov.wfn_str == "matern32":
+        s3d = np.sqrt(3.0) * d
+        return sv * (1.0 + s3d) * np.exp(-s3d)
+    raise ValueError(cov.wfn_str)
 
 
 def _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu):
@@ -47,7 +71,7 @@ def _prior_cholesky_times_z(X, cov, noise_var, Z, use_gpu):
     K = np.empty((n, n))
     step = 2048
     for s in range(0, n, step):
-        K[s:s + step] = hostkernels.kernel_matrix(X[s:s + step], X, cov)
+        K[s:s + step] = prior_kernel_matrix(X[s:s + step], X, cov)
     K[np.diag_indices(n)] += noise_var
     L, info = lapack.dpotrf(K, lower=1, overwrite_a=1)
     if info != 0:

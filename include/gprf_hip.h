@@ -106,6 +106,16 @@ int gprf_set_split_tree(gprf_ctx *ctx, int32_t n_nodes, int32_t dim, int32_t lon
                         const double *center, const double *split, const int32_t *left, const int32_t *right,
                         const int32_t *leaf_block);
 
+/* compute_neighbors (gprf.py:119-150): for every candidate block pair (cand_ij: n_cand rows (i, j)), decides whether the
+ * largest |k(x_p, x_q)| / signal_var over p in block i, q in block j exceeds `threshold` (keep_out[c] = 1) — the
+ * reference's `np.max(np.abs(self.kernel(X1, X2=X2) / wfn_var)) > threshold` with the kernel of gprf_set_theta.  Blocks
+ * as in gprf_set_blocks (CSR; they need not be installed).  The caller supplies the candidates — all pairs j < i like
+ * the reference, or a pruned superset (gprf_amd/neighbors.py prunes by bounding boxes / spherical caps).  max_out
+ * (may be NULL): the exact maxima, without the early exit.  One-time setup work: allocates and frees its buffers. */
+int gprf_pair_kernel_max(gprf_ctx *ctx, const double *X, int32_t n_blocks, const int64_t *block_ptr,
+                         const int32_t *point_idx, double threshold, int32_t n_cand, const int32_t *cand_ij,
+                         int32_t *keep_out, double *max_out);
+
 /* self.neighbors (gprf.py:112,212): n_pairs rows (i, j); each becomes one joint unit with block i's rows
  * first (gprf.py:322).  Bethe weights 1 - deg(i) for the unaries are derived here
  * (compute_neighbor_count gprf.py:152-157; llgrad gprf.py:253-254, 264, 287).  For local=False pass all

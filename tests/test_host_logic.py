@@ -6,7 +6,7 @@ import pytest
 from gprf_amd import Blocker, grid_centers, pair_distances
 from gprf_amd.gprf import _csr_from_block_idxs
 from gprf_amd import objective as pobj
-from gprf_amd import hostkernels
+from gprf_amd.synthetic import prior_kernel_matrix
 from gprf_amd.cov import GPCov
 from oracle import harness_ref as H
 from oracle.vector_tree import VectorTree
@@ -125,14 +125,15 @@ def test_log_line_format(tmp_path):
     assert lines[-1].startswith("optimization finished after")
 
 
-def test_host_kernels_match_oracle_c():
+def test_input_recipe_kernels_match_oracle_c():
+    """The covariance the synthetic outputs are drawn from (gprf_amd.synthetic.prior_kernel_matrix) is the oracle's."""
     rng = np.random.RandomState(3)
     X = rng.rand(30, 2)
     c = GPCov([1.4], [0.2, 0.3], "euclidean", "se")
-    assert np.allclose(hostkernels.kernel_matrix(X, X, c), VectorTree(None, 1, "euclidean", [0.2, 0.3], "se", [1.4]).kernel_matrix(X, X, False), rtol=1e-14)
+    assert np.allclose(prior_kernel_matrix(X, X, c), VectorTree(None, 1, "euclidean", [0.2, 0.3], "se", [1.4]).kernel_matrix(X, X, False), rtol=1e-14)
     X3 = np.stack([130 + rng.randn(20), -2 + rng.randn(20), np.abs(rng.randn(20)) * 30], axis=1)
     c = GPCov([0.9], [40.0, 20.0], "lld", "matern32")
-    assert np.allclose(hostkernels.kernel_matrix(X3, X3, c), VectorTree(None, 1, "lld", [40.0, 20.0], "matern32", [0.9]).kernel_matrix(X3, X3, False), rtol=1e-12)
+    assert np.allclose(prior_kernel_matrix(X3, X3, c), VectorTree(None, 1, "lld", [40.0, 20.0], "matern32", [0.9]).kernel_matrix(X3, X3, False), rtol=1e-12)
 
 
 def test_synthetic_recipe_matches_oracle_recipe():
@@ -148,51 +149,64 @@ def test_synthetic_recipe_matches_oracle_recipe():
     assert a.x_prior(a.X_obs.flatten() + 0.01)[0] == b.x_prior(b.X_obs.flatten() + 0.01)[0]
 
 
-def test_threshold_neighbors_pruned_equals_exhaustive_oracle():
-    """GPRF.compute_neighbors' host routine (bounding-box pruning) returns exactly the oracle's exhaustive pair list
-    (gprf.py:119-150), in the same order, for both kernels, several thresholds, anisotropic lengthscales, empty
-    blocks and blocks that interleave (boxes overlap)."""
-    from gprf_amd import GPCov, Blocker, grid_centers
-    from gprf_amd.hostkernels import threshold_neighbors
-    from oracle.gprf_ref import GPRFRef
-    from oracle.vector_tree import GPCov as OC
+def _cases_euclid():
+    from gprf_amd import Blocker, grid_centers
     rng = np.random.RandomState(4)
     X = rng.rand(1200, 2)
-    Y = rng.randn(1200, 2)
     b = Blocker(grid_centers(36))
     blocks = [np.asarray(i) for i in b.block_clusters(X)]
     blocks[7] = np.zeros(0, dtype=np.int64)                         # an empty block
     blocks[3], blocks[20] = np.concatenate([blocks[3][::2], blocks[20][::2]]), np.concatenate([blocks[3][1::2], blocks[20][1::2]])
-    for wfn, ls, thr in (("se", [0.05, 0.08], 1e-3), ("se", [0.12, 0.03], 0.3), ("matern32", [0.04, 0.04], 1e-2),
-                         ("se", [0.05, 0.05], 1.0), ("se", [0.5, 0.5], 1e-6)):
-        got = threshold_neighbors(X, blocks, GPCov([1.3], ls, "euclidean", wfn), thr)
-        ref = GPRFRef(X, Y, None, OC([1.3], ls, "euclidean", wfn), 0.01, block_idxs=blocks, neighbors=[])
-        ref.compute_neighbors(threshold=thr)
-        assert got == [(int(i), int(j)) for (i, j) in ref.neighbors], (wfn, ls, thr)
+    cases = (("se", [0.05, 0.08], 1e-3), ("se", [0.12, 0.03], 0.3), ("matern32", [0.04, 0.04], 1e-2),
+             ("se", [0.05, 0.05], 1.0), ("se", [0.5, 0.5], 1e-6))
+    return X, blocks, cases
 
 
-def test_threshold_neighbors_lld_cap_pruning_equals_exhaustive_oracle():
-    """Same for the seismic distance: spherical-cap + depth-range pruning returns the oracle's exhaustive pair list,
-    including blocks across the date line, near a pole, an empty block and two interleaved blocks."""
-    from gprf_amd import GPCov, seismic
-    from gprf_amd.hostkernels import threshold_neighbors
-    from oracle.gprf_ref import GPRFRef
-    from oracle.vector_tree import GPCov as OC
+def _cases_lld():
+    from gprf_amd import seismic
     X = seismic.synthetic_events(1500, seed=2)
     rng = np.random.RandomState(0)
     polar = np.stack([rng.uniform(-180, 180, 60), rng.uniform(86, 89.9, 60), rng.exponential(30, 60)], axis=1)
     X = np.concatenate([X, polar])
-    Y = np.zeros((len(X), 1))
     blocks, _ = seismic.pdtree_cluster(X, blocksize=70)
     blocks = [np.asarray(b) for b in blocks]
     blocks[5] = np.zeros(0, dtype=np.int64)
     blocks[2], blocks[9] = np.concatenate([blocks[2][::2], blocks[9][::2]]), np.concatenate([blocks[2][1::2], blocks[9][1::2]])
+    cases = (("matern32", [40.0, 40.0], 0.6), ("matern32", [150.0, 20.0], 0.3), ("se", [300.0, 50.0], 1e-3),
+             ("matern32", [40.0, 40.0], 1.0), ("matern32", [2000.0, 500.0], 1e-4))
+    return X, blocks, cases
+
+
+@pytest.mark.parametrize("dfn", ["euclidean", "lld"])
+def test_candidate_block_pairs_cover_the_exhaustive_oracle_list(dfn):
+    """GPRF.compute_neighbors' host half (geometric pruning, no kernel evaluation) never loses a pair: the oracle's
+    exhaustive list (gprf.py:119-150) is a subsequence of the candidates, which come in the reference's loop order —
+    both kernels, several thresholds, anisotropic lengthscales, empty blocks, interleaved blocks (boxes overlap), blocks
+    across the date line and near a pole.  The pruning is worth something: far fewer candidates than block pairs.  (The
+    device half, and the equality of the final list, is tests/test_gpu_neighbors.py.)"""
+    from gprf_amd import GPCov
+    from gprf_amd.neighbors import candidate_block_pairs
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    X, blocks, cases = _cases_euclid() if dfn == "euclidean" else _cases_lld()
+    Y = np.zeros((len(X), 1))
+    sv = 1.3 if dfn == "euclidean" else 0.7
     total = 0
-    for wfn, ls, thr in (("matern32", [40.0, 40.0], 0.6), ("matern32", [150.0, 20.0], 0.3), ("se", [300.0, 50.0], 1e-3),
-                         ("matern32", [40.0, 40.0], 1.0), ("matern32", [2000.0, 500.0], 1e-4)):
-        got = threshold_neighbors(X, blocks, GPCov([0.7], ls, "lld", wfn), thr)
-        ref = GPRFRef(X, Y, None, OC([0.7], ls, "lld", wfn), 0.1, block_idxs=blocks, neighbors=[])
+    for wfn, ls, thr in cases:
+        if dfn == "euclidean" and wfn == "matern32":
+            continue                                     # (the library pairs matern32 with the lld distance only)
+        cand = candidate_block_pairs(X, blocks, GPCov([sv], ls, dfn, wfn), thr)
+        ref = GPRFRef(X, Y, None, OC([sv], ls, dfn, wfn), 0.1, block_idxs=blocks, neighbors=[])
         ref.compute_neighbors(threshold=thr)
-        assert got == [(int(i), int(j)) for (i, j) in ref.neighbors], (wfn, ls, thr)
-        total += len(got)
+        want = [(int(i), int(j)) for (i, j) in ref.neighbors]
+        assert cand == sorted(cand, key=lambda p: (p[0], p[1])) and len(set(cand)) == len(cand)
+        it = iter(cand)
+        assert all(p in it for p in want), (wfn, ls, thr)        # subsequence, same order
+        assert all(len(blocks[i]) and len(blocks[j]) and j < i for (i, j) in cand)
+        if thr == 1.0:
+            assert cand == []
+        total += len(want)
+        nb = len(blocks)
+        if thr >= 1e-3 and max(ls) < 1000:
+            assert len(cand) < 0.5 * nb * (nb - 1) / 2
     assert total > 50
