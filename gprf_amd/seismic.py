@@ -203,9 +203,10 @@ class SeismicObjective(object):
             self.gprf.update_covs(FC)
         try:
             ll, gX, gC = self.gprf.llgrad(local=True, grad_X=self.gradX, grad_cov=self.gradC)
-        except Exception:
+        except np.linalg.LinAlgError:
             # run_seismic.py:155-159: a failed evaluation (a block that is not positive definite even with jitter)
-            # is answered with a huge objective and a random direction
+            # is answered with a huge objective and a random direction.  Only THAT failure: a library / HIP error, or a
+            # re-partition that grows a unit past GPRF_MAX_UNIT points (GprfHipError), propagates to the caller
             return 1e10, np.random.randn(*x.shape)
         pieces = []
         if self.gradX:

@@ -86,4 +86,5 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
-                assert "oracle/" not in src and "oracle." not in src.replace("oracle.", "oracle.") or "oracle" not in src, f
+                # nor reaches it any other way: importlib / __import__ / a path or a shared library under oracle/
+                assert not re.search(r"import_module\(\s*['\"]oracle|__import__\(\s*['\"]oracle|oracle/\w|libtreegp|oracle\.\w+\s*\(", src), f

@@ -50,9 +50,9 @@ def _oracle(sdata, local_dist):
 # Bethe weights (1 - deg_i up to -7, plus 8 pair terms per point) scale that to ~1e-7 on the GPRF objective
 # (Numerics).  Two independent fp64 evaluations therefore cannot agree to 1e-8 here.  What is
 # required instead: (a) the GPU is as close to the TRUE gradient as the reference path is (asserted below on
-# the full gradient: <= 1.5x the oracle's own error), and (b) GPU and oracle agree to
-# 2.5e-13 * max|gradX| * (1 + max Bethe degree)  (4.3e-8 local, 4.5e-7 with the 8-neighbourhood), i.e. to within
-# their common rounding floor.
+# the full gradient and, unit by unit, on pair units: <= 1.5x the oracle's own error), and (b) GPU and oracle agree
+# to twice the difference measured in round 1 (4e-8 local, 3e-7 with the 8-neighbourhood), i.e. to within their
+# common rounding floor with no room for a regression.
 
 
 def _truth(sdata, local_dist):
@@ -93,8 +93,9 @@ def test_gradient_against_oracle_and_extended_precision(sdata, local_dist):
           % (local_dist, gmax, e_go, e_gt, e_ot, abs(ll - o_ll) / abs(o_ll), abs(float(ll - t_ll)) / abs(float(t_ll)),
              abs(float(o_ll - t_ll)) / abs(float(t_ll))))
     assert e_gt <= 1.5 * e_ot                      # (a) as accurate as the reference CPU path
-    max_deg = 0 if local_dist == 1.0 else 8         # a point's gradient sums its block's unary x (1-deg) and deg pair terms
-    assert e_go <= 2.5e-13 * gmax * (1 + max_deg)  # (b) agreement at the common rounding floor
+    # (b) agreement at the common rounding floor: at most TWICE what round 1 measured on MI355X (1.94e-8 without /
+    # 1.52e-7 with the 342 pair units: profiles/r01_final_pytest_gpu.log) — a 2x regression fails
+    assert e_go <= (4e-8 if local_dist == 1.0 else 3e-7)
     assert np.isclose(ll, o_ll, rtol=1e-12)
     assert abs(float(ll - t_ll)) <= 1e-12 * abs(float(t_ll))
     assert np.allclose(gC, o_gC, rtol=1e-9)
@@ -138,3 +139,34 @@ def test_directional_fd_and_sum_rule(sdata):
     tot = sum(ctx.debug_fetch(l, 5)[0] for l in range(ctx.num_units()[1]))
     assert np.isclose(ll_local, tot, rtol=1e-13)
     gl.close()
+
+
+def test_pair_units_against_extended_precision_one_by_one(sdata):
+    """Per unit, not only on the assembled gradient: for pair units of the north-star configuration (the largest, the
+    smallest and a seeded sample) the device's gradient rows are at most 1.5x as far from the 80-bit evaluation as the
+    oracle's (fp64 LAPACK) rows are — the GPU path is as accurate as the reference CPU path unit by unit."""
+    from ld_truth import unit_llgrad_ld
+    g = sdata.build_gprf(local_dist=0.1)
+    g.llgrad(grad_X=True)
+    ctx = g._ctx
+    ctx.debug_run(np.ascontiguousarray(sdata.X_obs), 6)
+    ref = _oracle(sdata, 0.1)
+    nb = g.n_blocks
+    sizes = np.array([ctx.debug_unit_shape(l)[0] for l in range(nb, nb + len(g.neighbors))])
+    rng = np.random.RandomState(11)
+    pick = sorted(set([int(np.argmax(sizes)), int(np.argmin(sizes))] + rng.choice(len(sizes), 6, replace=False).tolist()))
+    assert len(pick) >= 5
+    worst = 0.0
+    for q in pick:
+        i, j = g.neighbors[q]
+        idx = np.concatenate([g.block_idxs[i], g.block_idxs[j]])
+        m = len(idx)
+        d_gx = ctx.debug_fetch(nb + q, 4)[:m, :2]
+        _, o_gx, _ = ref.gaussian_llgrad(sdata.X_obs[idx], sdata.SY[idx], grad_X=True)
+        _, t_gx = unit_llgrad_ld(sdata.X_obs[idx], sdata.SY[idx], 0.01, 1.0, [0.06, 0.06])
+        e_gt = float(np.max(np.abs(d_gx - t_gx)))
+        e_ot = float(np.max(np.abs(o_gx - t_gx)))
+        worst = max(worst, e_gt / e_ot)
+        assert e_gt <= 1.5 * e_ot, (q, m, e_gt, e_ot)
+    print("pair units vs 80-bit: %d units (m %d..%d), worst |gpu-true| / |oracle-true| = %.2f" % (len(pick), sizes[pick].min(), sizes[pick].max(), worst))
+    g.close()

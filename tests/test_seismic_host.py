@@ -64,8 +64,9 @@ def test_priors_equal_reference_restatement():
 class _ScriptedGPRF(object):
     """Answers llgrad with a smooth function of what update_X / update_covs last received."""
 
-    def __init__(self, n, fail_at=None):
+    def __init__(self, n, fail_at=None, exc=None):
         self.n, self.calls, self.fail_at = n, 0, fail_at
+        self.exc = exc if exc is not None else np.linalg.LinAlgError("not positive definite")
         self.X, self.FC = None, None
 
     def update_X(self, X):
@@ -77,7 +78,7 @@ class _ScriptedGPRF(object):
     def llgrad(self, local=True, grad_X=False, grad_cov=False, **kw):
         self.calls += 1
         if self.fail_at == self.calls:
-            raise np.linalg.LinAlgError("not positive definite")
+            raise self.exc
         ll = -3.0
         gX, gC = np.zeros((0, 0)), np.zeros((0, 0))
         if self.X is not None:
@@ -134,6 +135,12 @@ def test_failed_evaluation_is_answered_like_the_reference():
     assert f == 1e10 and gr.shape == o.full0.shape and np.all(np.isfinite(gr))     # run_seismic.py:155-159
     f2, _ = o(o.full0)
     assert f2 < 1e9
+    # ... but only THAT failure: a library error (HIP error, a unit grown past GPRF_MAX_UNIT) is not swallowed
+    from gprf_amd import _capi
+    g = _ScriptedGPRF(n, fail_at=1, exc=_capi.GprfHipError("gprf_update_eval failed (-1): unit 3 has 1100 points"))
+    o = seismic.SeismicObjective(g, means.copy(), None, x_prior=seismic.make_x_prior(means, 2.0))
+    with pytest.raises(_capi.GprfHipError):
+        o(o.full0)
 
 
 def test_coincident_events_end_in_one_leaf_instead_of_splitting_forever():
