@@ -28,6 +28,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
+           "-Wl,--no-undefined",      # a symbol one source file declares and the other forgot to define fails HERE
            # k_potrf_reg keeps tiles in explicitly numbered AGPRs behind inline asm: the compiler must never park a
            # spilled VGPR in an AGPR of its own choosing (tests/test_isa_invariants.py checks the ISA)
            "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",

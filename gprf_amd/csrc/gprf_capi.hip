@@ -384,7 +384,7 @@ int rebuild_static(gprf_ctx *c) {
     if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(s));
     size_t nl1 = (size_t)std::max(nl, 1);
-    c->n_chunks = (c->n + 255) / 256;
+    c->n_chunks = (c->n + CHUNK - 1) / CHUNK;
     HIP_TRY(c, c->d_m.reserve(nl1));
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_offj.reserve(nl1));
@@ -766,7 +766,7 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     c->n = n; c->dx = dx; c->dy = dy; c->dist_id = dist_id; c->kern_id = kern_id; c->device = device;
     c->ndfn = se ? dx : 2;
     c->ncov = 2 + c->ndfn;
-    c->n_chunks = (n + 255) / 256;
+    c->n_chunks = (n + CHUNK - 1) / CHUNK;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return GPRF_ERR_HIP;

@@ -12,6 +12,7 @@ constexpr int MAX_T = MAX_MP / TILE;
 constexpr int YPAD = 64;          // dy padded to 4 column tiles
 constexpr int XPAD = 4;           // dx padded (dx <= 3)
 constexpr int GC_SLOTS = 8;       // per-(unit, column-tile) hyper-gradient partials
+constexpr int CHUNK = 64;         // points per workgroup of the partition kernels (= per row of BuildTab::cnt)
 constexpr int MAX_TB = MAX_T / 4;   // 64-point blocks per unit edge (k_grad2's row-sum slab)
 
 // Kernel hyper-parameters, passed by value.  theta = [nv, sv, ls...] (gprf.py:160-164).
@@ -46,7 +47,7 @@ struct UnitTab {
 struct BuildTab {
     int32_t *assign;         // [n] block of every point, -1 = in no block
     int32_t *posb;           // [n] position of the point inside its block
-    int32_t *rank;           // [n] scratch: position among the points of the same block within its 256-point chunk
+    int32_t *rank;           // [n] scratch: position among the points of the same block within its CHUNK-point chunk
     int32_t *cnt;            // [n_chunks][n_blocks] points of a block per chunk -> (k_unit_scan) exclusive prefix over chunks
     int32_t *bsize;          // [n_blocks] points per block
     const int32_t *unit_bi;  // [n_local] first block of the unit

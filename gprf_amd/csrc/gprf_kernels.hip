@@ -2276,23 +2276,47 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
             for (int i = threadIdx.x; i < at.mirror_n; i += 256) at.mirror_dst[i] = at.mirror_src[i];
         return;
     }
-    long idx = (long)(blockIdx.x - 1) * 256 + threadIdx.x;
-    if (idx >= (long)n * dx) return;
-    int p = (int)(idx / dx), d = (int)(idx % dx);
-    double v = 0.0;
-    int b = at.assign[p];
-    if (want_gx && b >= 0 && !at.ctl[CTL_OVERFLOW]) {
-        // the point's rows: position posb[p] of its block inside every local unit that contains the block, in
-        // ascending unit order (gprf.py:258-273: unary term first, then the pair terms in neighbour order)
-        int pos = at.posb[p];
-        for (int e = at.bu_ptr[b]; e < at.bu_ptr[b + 1]; ++e) {
-            int ent = at.bu_ent[e];
+    // gradX: 32 points per workgroup, 8 lanes per point — one per unit that contains the point's block, eight at a time
+    // (the row lookups are chains of dependent loads: spread over lanes they overlap) — and the terms of a point are
+    // added up by ONE lane in ascending unit order (gprf.py:258-273: unary term first, then the pair terms in neighbour
+    // order): bit-reproducible, and the same sum whatever the launch looks like.
+    __shared__ double term[32][8][3];
+    __shared__ int s_maxcnt;
+    int t = threadIdx.x, i = t >> 3, e = t & 7;
+    int p = (blockIdx.x - 1) * 32 + i;
+    bool live = want_gx && p < n && !at.ctl[CTL_OVERFLOW];
+    int b = live ? at.assign[p] : -1;
+    int e0 = 0, cnt = 0, pos = 0;
+    if (b >= 0) {
+        e0 = at.bu_ptr[b];
+        cnt = at.bu_ptr[b + 1] - e0;
+        pos = at.posb[p];
+    }
+    if (t == 0) s_maxcnt = 0;
+    __syncthreads();
+    if (e == 0 && cnt > 0) atomicMax(&s_maxcnt, cnt);
+    __syncthreads();
+    int maxcnt = s_maxcnt;
+    double v = 0.0;                           // lane e < dx of point i carries coordinate e
+    for (int k0 = 0; k0 < maxcnt; k0 += 8) {
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+        if (k0 + e < cnt) {
+            int ent = at.bu_ent[e0 + k0 + e];
             int u = ent >> 1;
             int row = ut.row_off[u] + ((ent & 1) ? at.off_j[u] : 0) + pos;
-            v += ut.weight[u] * pl.gXu[(size_t)row * XPAD + d];
+            double w = ut.weight[u];
+            const double *gr = pl.gXu + (size_t)row * XPAD;
+            g0 = w * gr[0]; g1 = w * gr[1]; g2 = w * gr[2];
         }
+        term[i][e][0] = g0; term[i][e][1] = g1; term[i][e][2] = g2;
+        __syncthreads();
+        if (e < dx) {
+            int kn = cnt - k0 < 8 ? cnt - k0 : 8;
+            for (int k = 0; k < kn; ++k) v += term[i][k][e];
+        }
+        __syncthreads();
     }
-    out[1 + idx] = v;
+    if (p < n && e < dx) out[1 + (size_t)p * dx + e] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2326,8 +2350,8 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 // ------------------------------------------------------------------------------------------------
 // Re-blocking on the device (gprf.py:169-174: update_X re-runs block_fn before every evaluation).
 //
-// partition_tail: what both partition kernels (nearest centre, split tree) end with.  One workgroup = one chunk of
-// 256 consecutive points.  Besides the new block of its point each thread leaves
+// partition_tail: what both partition kernels (nearest centre, split tree) end with.  One workgroup (one wave) = one
+// chunk of CHUNK = 64 consecutive points (n / 64 workgroups spread a small problem over enough CUs).  Besides the new block of its point each thread leaves
 //   rank[p]       = points of the same block earlier in the chunk,
 //   cnt[chunk][b] = points of block b in the chunk (written by the block's last point of the chunk; the workgroup
 //                   zeroes its own row first),
@@ -2336,17 +2360,17 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 // ctl[CTL_CHANGED] with this evaluation's epoch (no reset needed between evaluations).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void partition_tail(int p, int n, int best, const BuildTab &bt, int epoch,
-                                               int *keys /* LDS [256], 16-byte aligned */) {
+                                               int *keys /* LDS [CHUNK], 16-byte aligned */) {
     int t = threadIdx.x;
     int *row = bt.cnt + (size_t)blockIdx.x * bt.n_blocks;
-    for (int b = t; b < bt.n_blocks; b += 256) row[b] = 0;
+    for (int b = t; b < bt.n_blocks; b += CHUNK) row[b] = 0;
     keys[t] = p < n ? best : -1;
     __syncthreads();
     if (p >= n) return;
     int before = 0, total = 0;
     const int4 *k4 = reinterpret_cast<const int4 *>(keys);
-#pragma unroll 8
-    for (int q4 = 0; q4 < 64; ++q4) {
+#pragma unroll
+    for (int q4 = 0; q4 < CHUNK / 4; ++q4) {
         int4 k = k4[q4];                           // wave-uniform address: LDS broadcast
         int q = 4 * q4;
         int s0 = k.x == best, s1 = k.y == best, s2 = k.z == best, s3 = k.w == best;
@@ -2371,13 +2395,13 @@ constexpr int ASSIGN_TILE = 512;
 // would live in scratch memory.)  Xcopy: the kernel's own copy of the points in HBM for the kernels that follow (X
 // itself may be pinned host memory read over the fabric).
 template <int DX>
-__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, double *__restrict__ Xcopy,
+__global__ __launch_bounds__(CHUNK) void k_assign(const double *__restrict__ X, double *__restrict__ Xcopy,
                                                 const double *__restrict__ cs, const double *__restrict__ c2, int nc,
                                                 BuildTab bt, int epoch) {
-    __shared__ __attribute__((aligned(16))) int keys[256];
+    __shared__ __attribute__((aligned(16))) int keys[CHUNK];
     __shared__ double scs[DX * ASSIGN_TILE], sc2[ASSIGN_TILE];
     int n = bt.n;
-    int p = blockIdx.x * 256 + threadIdx.x;
+    int p = blockIdx.x * CHUNK + threadIdx.x;
     double x[DX], x2 = 0.0;
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
@@ -2393,7 +2417,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, do
     for (int k0 = 0; k0 < nc; k0 += ASSIGN_TILE) {
         int kn = nc - k0 < ASSIGN_TILE ? nc - k0 : ASSIGN_TILE;
         __syncthreads();
-        for (int e = threadIdx.x; e < kn; e += 256) {
+        for (int e = threadIdx.x; e < kn; e += CHUNK) {
 #pragma unroll
             for (int d = 0; d < DX; ++d) scs[d * ASSIGN_TILE + e] = cs[(size_t)d * nc + k0 + e];
             sc2[e] = c2[k0 + e];
@@ -2419,14 +2443,14 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ X, do
 // longitude first moved to [-22, 338) like the reference's `(lon + 22) % 360 - 22`.  The projection is accumulated
 // column by column with separately rounded multiplies and adds, which is how gprf_amd/seismic.py builds and routes
 // (numpy element-wise ops): bit-identical decisions, including the median point whose projection equals the split.
-__global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, double *__restrict__ Xcopy, int dx, int dim,
+__global__ __launch_bounds__(CHUNK) void k_route(const double *__restrict__ X, double *__restrict__ Xcopy, int dx, int dim,
                                                int lon_wrap, const double *__restrict__ vec,
                                                const double *__restrict__ center, const double *__restrict__ split,
                                                const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                const int32_t *__restrict__ leaf_block, BuildTab bt, int epoch) {
-    __shared__ __attribute__((aligned(16))) int keys[256];
+    __shared__ __attribute__((aligned(16))) int keys[CHUNK];
     int n = bt.n;
-    int p = blockIdx.x * 256 + threadIdx.x;
+    int p = blockIdx.x * CHUNK + threadIdx.x;
     int best = 0;
     if (p < n) {
         double x[3] = {0.0, 0.0, 0.0};              // dx <= 3 (gprf_create); fixed-bound loops keep x[] in registers
@@ -2458,7 +2482,7 @@ __global__ __launch_bounds__(256) void k_route(const double *__restrict__ X, dou
 void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt,
                    int epoch, hipStream_t s) {
     if (bt.n == 0) return;
-    dim3 g(bt.n_chunks), b(256);
+    dim3 g(bt.n_chunks), b(CHUNK);
     if (dx == 1) hipLaunchKernelGGL((k_assign<1>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
     else if (dx == 2) hipLaunchKernelGGL((k_assign<2>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
     else hipLaunchKernelGGL((k_assign<3>), g, b, 0, s, X, Xcopy, cs, c2, nc, bt, epoch);
@@ -2468,7 +2492,7 @@ void launch_route(const double *X, double *Xcopy, int dx, int dim, int lon_wrap,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
                   const BuildTab &bt, int epoch, hipStream_t s) {
     if (bt.n == 0) return;
-    hipLaunchKernelGGL(k_route, dim3(bt.n_chunks), dim3(256), 0, s, X, Xcopy, dx, dim, lon_wrap, vec, center, split, left,
+    hipLaunchKernelGGL(k_route, dim3(bt.n_chunks), dim3(CHUNK), 0, s, X, Xcopy, dx, dim, lon_wrap, vec, center, split, left,
                        right, leaf_block, bt, epoch);
 }
 
@@ -2536,6 +2560,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
         }
         return;
     }
+    // (the unit sizes stay in LDS for the second pass: every global round trip of this one-workgroup kernel is exposed)
+    constexpr int M_LDS = 8192;
+    __shared__ int s_m[M_LDS];
     if (t == 0) s_maxm = 0;
     __syncthreads();
     long long rows = 0, mat = 0;
@@ -2551,10 +2578,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
         long long a = mp, b = mp * mp, ta, tb;
         wg_exscan2(a, b, sh, &ta, &tb);
         if (l < bt.n_local) {
+            long long r0 = rows + a;
             bt.m[l] = m;
             bt.off_j[l] = mi;
-            bt.row_off[l] = (int32_t)(rows + a);
+            bt.row_off[l] = (int32_t)r0;
             bt.mat_off[l] = mat + b;
+            if (l < M_LDS) s_m[l] = m;
             atomicMax(&s_maxm, m);
         }
         rows += ta;
@@ -2574,7 +2603,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
             long long big = 0, one = 0, tb_, to_;
             if (k < bt.n_local) {
                 u = bt.ids[k];
-                big = ((bt.m[u] + 15) >> 4) > bt.small_maxT ? 1 : 0;
+                int mu = u < M_LDS ? s_m[u] : bt.m[u];
+                big = ((mu + 15) >> 4) > bt.small_maxT ? 1 : 0;
                 one = 1;
             }
             long long isbig = big, pos = one;
@@ -2587,16 +2617,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
         }
         over = over || nbig > bt.grid_big || (bt.n_local - nbig) > bt.grid_small;
     }
-    for (int l = t; l < bt.n_local; l += SCAN_THREADS) {
-        if (over) {
-            bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0;
-        } else {
-            // the unit's padding rows of the coordinate pool: zero (k_scatter_x writes the rows below m only)
-            int m = bt.m[l], mp = (m + 15) & ~15;
-            double *xr = bt.Xu + (size_t)(bt.row_off[l] + m) * bt.xstride;
-            for (int e = 0; e < (mp - m) * bt.xstride; ++e) xr[e] = 0.0;
-        }
-    }
+    if (over)
+        for (int l = t; l < bt.n_local; l += SCAN_THREADS) { bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0; }
     if (t == 0) {
         bt.ctl[CTL_OVERFLOW] = over ? 1 : 0;
         bt.ctl[CTL_NBIG] = over ? 0 : (int32_t)nbig;
@@ -2615,14 +2637,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
 // being rebuilt, the position itself (from the chunk ranks) and the unit row -> point table.
 __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__restrict__ X, int dx, int geo,
                                                    int from_chunks, int force, int epoch) {
+    bool rebuild = rebuilding(bt, force, epoch);
+    int nblk_pts = (bt.n + 255) / 256;
+    if ((int)blockIdx.x >= nblk_pts) {
+        // the workgroups behind the points': when the tables were rebuilt, the units' padding rows (m .. mp) of the
+        // coordinate pool are zeroed — 16 lanes per unit (one single-workgroup kernel doing this was store-issue bound)
+        if (!rebuild || bt.ctl[CTL_OVERFLOW]) return;
+        int idx = ((int)blockIdx.x - nblk_pts) * 256 + threadIdx.x;
+        int u = idx >> 4, r = idx & 15;
+        if (u >= bt.n_local) return;
+        int m = bt.m[u];
+        if (m + r < ((m + 15) & ~15)) {
+            double *xr = bt.Xu + (size_t)(bt.row_off[u] + m + r) * bt.xstride;
+            for (int e = 0; e < bt.xstride; ++e) xr[e] = 0.0;
+        }
+        return;
+    }
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= bt.n) return;
     int b = bt.assign[p];
     if (b < 0) return;
-    bool rebuild = rebuilding(bt, force, epoch);
     int pos;
     if (rebuild && from_chunks) {
-        pos = bt.cnt[(size_t)blockIdx.x * bt.n_blocks + b] + bt.rank[p];
+        pos = bt.cnt[(size_t)(p / CHUNK) * bt.n_blocks + b] + bt.rank[p];
         bt.posb[p] = pos;
     } else {
         pos = bt.posb[p];
@@ -2666,8 +2703,8 @@ void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epo
 
 void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, int from_chunks, int force, int epoch,
                       hipStream_t s) {
-    if (bt.n == 0) return;
-    hipLaunchKernelGGL(k_scatter_x, dim3(bt.n_chunks), dim3(256), 0, s, bt, X, dx, dist_id == 1 ? 1 : 0, from_chunks,
+    if (bt.n == 0 && bt.n_local == 0) return;
+    hipLaunchKernelGGL(k_scatter_x, dim3((bt.n + 255) / 256 + (bt.n_local * 16 + 255) / 256), dim3(256), 0, s, bt, X, dx, dist_id == 1 ? 1 : 0, from_chunks,
                        force, epoch);
 }
 
@@ -2942,8 +2979,7 @@ void launch_done(int32_t *flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, hipStream_t s) {
-    long work = (long)n * kp.dx;
-    int blocks = 1 + (int)((work + 255) / 256);
+    int blocks = 1 + (n + 31) / 32;
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out);
 }
 
