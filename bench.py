@@ -362,11 +362,11 @@ def main():
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
         try:
             tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
-            key = {"potrf": "k_potrf_reg_gen", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
+            key = {"potrf": "k_potrf_dual", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 roof["traffic"] = tr[key]["bytes_per_launch"]
                 roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), profiled at commit %s; this run: %s" % (
-                    TRAFFIC_FILE, tr.get("commit", "?"), git_head())
+                    TRAFFIC_FILE, tr.get("commit", "?"), git_head() or "no git on this box")
         except Exception:
             pass
         roof["avg_launch_ms"] = stage[dom]
