@@ -83,6 +83,9 @@ struct gprf_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // second queue: the Cholesky instantiation that runs beside the main one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf<uint32_t> d_side;               // fork / join words of the side queue (stream memory operations)
+    uint32_t side_seq = 0;
+    bool side_values = false;             // the device supports hipStreamWaitValue32
     std::string err;
 
     // host-side model state (what the reference keeps on the GPRF object)
@@ -591,7 +594,13 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
     if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
     mark();
-    if (stop_after >= 1) launch_potrf(ut, pl, kp, gen, s, c->stream2, c->ev_fork, c->ev_join);
+    if (stop_after >= 1) {
+        SideQueue side;
+        side.s2 = c->stream2; side.ev_fork = c->ev_fork; side.ev_join = c->ev_join;
+        side.words = c->side_values ? c->d_side.p : nullptr;
+        side.seq = ++c->side_seq;
+        launch_potrf(ut, pl, kp, gen, s, side);
+    }
     mark();
     if (stop_after >= 2) launch_solve(ut, pl, kp, s);
     mark();
@@ -777,6 +786,13 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
         gprf_destroy(c);
         return GPRF_ERR_HIP;
     }
+    {
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
+        if (const char *e = getenv("GPRF_SIDE_EVENTS")) { if (e[0] == '1') can = 0; }      // diagnostics: force events
+        if (can && c->d_side.reserve(16, 1.0) == hipSuccess && hipMemset(c->d_side.p, 0, 16 * sizeof(uint32_t)) == hipSuccess)
+            c->side_values = true;
+    }
     size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
     if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
         c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
@@ -799,7 +815,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
     c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
-    c->d_cs.release(); c->d_c2.release();
+    c->d_cs.release(); c->d_c2.release(); c->d_side.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
     c->d_tleaf.release();
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();

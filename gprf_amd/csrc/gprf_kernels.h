@@ -138,9 +138,16 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
 bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
 int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
-// s2 / ev_fork / ev_join: a second queue (and two events) for the instantiation that runs beside the main one; s2 = nullptr: one launch
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, hipStream_t s2,
-                  hipEvent_t ev_fork, hipEvent_t ev_join);
+// The second queue for the instantiation that runs beside the main one, and how the two queues wait for each other:
+// events (11 us per dependency measured, scripts/stream_dep_latency.hip) and, for the join, a stream memory operation on a
+// device word (hipStreamWriteValue32 / hipStreamWaitValue32: 4 us) where the device supports it.  s2 = nullptr: one launch.
+struct SideQueue {
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t *words = nullptr;      // [2] device words: fork, join
+    uint32_t seq = 0;               // value of this evaluation (monotonic)
+};
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,

@@ -2740,9 +2740,9 @@ bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation 
 }
 int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
 
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, hipStream_t s2,
-                  hipEvent_t ev_fork, hipEvent_t ev_join) {
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side) {
     if (ut.n_ids == 0) return;
+    hipStream_t s2 = side.s2;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
     int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
     // The register-resident kernel holds a whole CU per unit (one wave per SIMD): it wins on latency while the
@@ -2770,9 +2770,21 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 if (lds_needs_optin(2, lds))
                     (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (s2 != s) {
-                    (void)hipEventRecord(ev_fork, s);
-                    (void)hipStreamWaitEvent(s2, ev_fork, 0);
+                // measured on the north-star configuration (stage time, us): events both ways 131; memory operations
+                // both ways 177; fork by memory operation + join by event 181; fork by event + join by memory operation
+                // 121 (the write in front of the large-unit kernel holds that kernel back; the wait in front of the
+                // solve does not).  GPRF_SIDE_MODE = 0 / 1 / 2 / 3 selects them in that order (diagnostics).
+                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : 3; }();
+                const bool fork_values = side.words && (side_mode == 1 || side_mode == 2);
+                const bool join_values = side.words && (side_mode == 1 || side_mode == 3);
+                if (s2 != s) {      // fork: the side queue starts when everything enqueued on s so far is done
+                    if (fork_values) {
+                        (void)hipStreamWriteValue32(s, side.words, side.seq, 0);
+                        (void)hipStreamWaitValue32(s2, side.words, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+                    } else {
+                        (void)hipEventRecord(side.ev_fork, s);
+                        (void)hipStreamWaitEvent(s2, side.ev_fork, 0);
+                    }
                 }
                 // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
                 // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
@@ -2783,9 +2795,14 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 if (ut.grid_small > 0)
                     hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.grid_small),
                                        dim3(POTRF_REG_WAVES * 64), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
-                if (s2 != s) {
-                    (void)hipEventRecord(ev_join, s2);
-                    (void)hipStreamWaitEvent(s, ev_join, 0);
+                if (s2 != s) {      // join
+                    if (join_values) {
+                        (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);
+                        (void)hipStreamWaitValue32(s, side.words + 1, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+                    } else {
+                        (void)hipEventRecord(side.ev_join, s2);
+                        (void)hipStreamWaitEvent(s, side.ev_join, 0);
+                    }
                 }
                 return;
             }
