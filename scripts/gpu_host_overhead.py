@@ -10,7 +10,7 @@ sd = SampledData(n=10500, ntrain=10000, lscale=0.06, obs_std=0.02, yd=50, seed=0
 sd.set_centers(grid_centers(100))
 g = sd.build_gprf(local_dist=0.5)
 rng = np.random.RandomState(0)
-Xs = [np.ascontiguousarray(sd.X_obs + 0.002 * k * rng.randn(*sd.X_obs.shape)) for k in range(10)]
+Xs = [np.ascontiguousarray(sd.X_obs + 2e-4 * k * rng.randn(*sd.X_obs.shape)) for k in range(10)]   # a few points change block
 for k in range(20):
     g.update_X(Xs[k % 10]); g.llgrad(grad_X=True)
 N = 300
