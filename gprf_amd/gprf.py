@@ -183,6 +183,14 @@ class GPRF(object):
         fn = self.block_fn
         if fn is None:
             return None
+        cached = getattr(self, "_router_cache", None)
+        if cached is not None and cached[0] is fn and cached[1] == self.n_blocks:
+            return cached[2]                     # (asked on every update_X: once per optimiser step)
+        router = self._find_device_router(fn)
+        self._router_cache = (fn, self.n_blocks, router)
+        return router
+
+    def _find_device_router(self, fn):
         from .blocking import Blocker
         blocker = getattr(fn, "__self__", None)
         tree = getattr(fn, "tree", None)
