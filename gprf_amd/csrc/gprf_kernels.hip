@@ -85,7 +85,8 @@ template <int DIST, int KERN>
 struct KernFn;
 
 // exp(x) for the covariance functions' arguments (x <= 0 in exact arithmetic; any finite x works): n = rint(x log2 e),
-// r = x - n ln2 (two-piece ln2, |r| <= 0.347), Taylor polynomial of degree 13 (truncation 4e-18 relative), ldexp.
+// r = x - n ln2 (two-piece ln2, |r| <= 0.347), Taylor polynomial of degree 13 (truncation 4e-18 relative) summed as
+// 1 + (r + r^2 q(r)), ldexp.
 // The library exp() spends half of its ~40 instructions moving polynomial coefficients into VGPRs for v_fmac; here
 // every Horner step is one v_fma_f64 with the coefficient as a scalar operand — 20 instructions.  That matters where
 // a wave is alone on its SIMD and generates kernel values itself (k_potrf_reg<.,.,true>).  NaN stays NaN, anything
@@ -121,9 +122,14 @@ __device__ __forceinline__ void exp_fast_v(const double (&x)[N], double (&y)[N])
     GPRF_EXP_STEP(1.0 / 24.0)
     GPRF_EXP_STEP(1.0 / 6.0)
     GPRF_EXP_STEP(0.5)
-    GPRF_EXP_STEP(1.0)
-    GPRF_EXP_STEP(1.0)
 #undef GPRF_EXP_STEP
+    // e^r = 1 + (r + r^2 q(r)): the Horner chain's rounding enters scaled by r^2 <= 0.12, the last two roundings are of
+    // r + r^2 q (|.| <= 0.41) and of the final sum — under 1 ulp in all (the plain Horner form's last two steps, each
+    // rounding a value near 1, left up to 4)
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = __builtin_fma(r[i] * r[i], p[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = 1.0 + p[i];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double v = __builtin_ldexp(p[i], (int)n[i]);
