@@ -119,6 +119,7 @@ struct gprf_ctx {
     template <typename T> struct View { T *p = nullptr; };
     View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
     DevBuf<int32_t> d_big_list, d_small_list;
+    DevBuf<SlotRec> d_srec, d_big_rec, d_small_rec;
     int grid_big = 0, grid_small = 0;     // launch sizes of the Cholesky's two lists (list lengths at the last sync + slack)
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
@@ -196,6 +197,7 @@ UnitTab make_tab(gprf_ctx *c) {
     t.ids = c->d_ids.p;
     t.n_ids = c->n_local;
     t.big_list = c->d_big_list.p; t.small_list = c->d_small_list.p; t.ctl = c->d_res.p;
+    t.srec = c->d_srec.p; t.big_rec = c->d_big_rec.p; t.small_rec = c->d_small_rec.p;
     t.grid_big = c->grid_big; t.grid_small = c->grid_small;
     return t;
 }
@@ -206,6 +208,7 @@ BuildTab make_build(gprf_ctx *c) {
     b.bsize = res_bsize(c);
     b.unit_bi = c->d_unit_bi.p; b.unit_bj = c->d_unit_bj.p; b.bu_ptr = c->d_bu_ptr.p; b.bu_ent = c->d_bu_ent.p;
     b.ids = c->d_ids.p; b.big_list = c->d_big_list.p; b.small_list = c->d_small_list.p;
+    b.srec = c->d_srec.p; b.big_rec = c->d_big_rec.p; b.small_rec = c->d_small_rec.p;
     b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE && potrf_dual_enabled()) ? potrf_small_maxT() : 0;
     b.grid_big = c->grid_big; b.grid_small = c->grid_small;
     b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
@@ -267,7 +270,11 @@ int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
     size_t tbm = (size_t)std::max((maxT + 3) / 4, 1);      // 64-point blocks per edge of the largest local unit
     HIP_TRY(c, c->d_logdet.reserve(nl1));
     HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
+#ifdef GPRF_WGTRACE
+    HIP_TRY(c, c->d_dbg.reserve(nl1 * 8 + 4 * GPRF_WGTRACE_MAX));     // + one (start, end, hw id, block) record per workgroup
+#else
     HIP_TRY(c, c->d_dbg.reserve(nl1 * 8));
+#endif
     HIP_TRY(c, c->d_gcpart.reserve(nl1 * (tbm * (tbm + 1) / 2) * GC_SLOTS));
     HIP_TRY(c, c->d_rowpart.reserve((size_t)rows * tbm * XPAD + 1, 1.0));
     HIP_TRY(c, c->d_colpart.reserve((size_t)rows * tbm * XPAD + 1, 1.0));
@@ -394,6 +401,9 @@ int rebuild_static(gprf_ctx *c) {
     HIP_TRY(c, c->d_matoff.reserve(nl1));
     HIP_TRY(c, c->d_big_list.reserve(nl1));
     HIP_TRY(c, c->d_small_list.reserve(nl1));
+    HIP_TRY(c, c->d_srec.reserve(nl1));
+    HIP_TRY(c, c->d_big_rec.reserve(nl1));
+    HIP_TRY(c, c->d_small_rec.reserve(nl1));
     HIP_TRY(c, c->d_assign.reserve((size_t)c->n + 1, 1.0));
     HIP_TRY(c, c->d_posb.reserve((size_t)c->n + 1, 1.0));
     HIP_TRY(c, c->d_rank.reserve((size_t)c->n + 1, 1.0));
@@ -813,7 +823,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
-    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
+    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
     c->d_cs.release(); c->d_c2.release(); c->d_side.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
@@ -1339,6 +1349,9 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
         case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;
         case 4: src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;
         case 6: src = c->d_dbg.p + (size_t)l * 8; len = 8; break;
+#ifdef GPRF_WGTRACE
+        case 11: src = c->d_dbg.p + (size_t)std::max(c->n_local, 1) * 8; len = 4 * GPRF_WGTRACE_MAX; break;
+#endif
         case 7: case 8: {   // per-block partials of the gradient reduction: mp x TBm x XPAD
             int64_t tbm = std::max((c->max_T + 3) / 4, 1);
             src = (what == 7 ? c->d_colpart.p : c->d_rowpart.p) + roff * tbm * XPAD;

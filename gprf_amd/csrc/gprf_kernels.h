@@ -25,7 +25,19 @@ struct KParams {
 
 // Per-unit tables (device pointers), one entry per LOCAL unit.  m / row_off / mat_off / off_j / upt are written ON THE
 // DEVICE from the partition (k_unit_scan, k_place): nothing about a re-blocking returns to the host.
+// One 16-byte record per launch slot: everything a workgroup needs to find its unit, in ONE load instead of the chain
+// ids[slot] -> m[u] -> row_off[u] -> mat_off[u] (four dependent memory round trips at the head of every workgroup of
+// every kernel: 12-17 k cycles before the first useful instruction, measured).  Written by k_build next to the tables.
+struct SlotRec {
+    int32_t u;          // local unit id
+    int32_t m;          // points (0 when the build overflowed)
+    int32_t row_off;    // = row_off[u]
+    uint32_t mat256;    // = mat_off[u] / 256 (mp is a multiple of 16, so every offset is a multiple of 256)
+};
+
 struct UnitTab {
+    const SlotRec *srec;     // [n_ids] in launch order (ids)
+    const SlotRec *big_rec, *small_rec;   // the same records in the order of big_list / small_list
     const int32_t *m;        // points in the unit (0 for every unit when the build overflowed the workspace: ctl)
     const int32_t *row_off;  // padded-row offset: sum of mp over previous units
     const int64_t *mat_off;  // element offset of the unit's mp x mp matrices in the U / W pools
@@ -56,6 +68,7 @@ struct BuildTab {
     const int32_t *bu_ent;   // ... as 2 * unit + side (side 1 = the block's rows come second in the unit)
     const int32_t *ids;      // [n_local] launch order (largest first at the last host build)
     int32_t *big_list, *small_list;   // [n_local] each: the units of more than / at most small_maxT tiles, in ids order
+    SlotRec *srec, *big_rec, *small_rec;   // [n_local] each: the launch-slot records (UnitTab)
     int small_maxT;          // 0 = no split
     int grid_big, grid_small;         // launch sizes the lists must fit
     int32_t *m;              // the UnitTab columns this build writes
@@ -85,6 +98,9 @@ constexpr int CTL_WORDS = 10;
 // spare doubles behind the last unit's matrix in the U / W / K pools (row-panel loads address whole 64-column
 // chunks; the lanes beyond the unit's edge are masked off, the slack keeps even an unmasked variant in bounds)
 constexpr size_t GPRF_POOL_SLACK = 512;
+
+// diagnostic builds (-DGPRF_WGTRACE=<kernel id>): workgroup records behind the per-unit stamps in Pools::dbg
+constexpr int GPRF_WGTRACE_MAX = 1 << 15;
 
 struct Pools {
     double *K;     // kernel matrices, row-major mp x mp per unit: k_fill writes the 64x64 blocks ti <= tj only

@@ -28,6 +28,7 @@
 namespace gprf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -66,6 +67,46 @@ __device__ __forceinline__ void lds_barrier() {
 // XCD-aware 1-D grid -> (unit slot, part): workgroups are dealt round-robin over the 8 XCDs (each with its own
 // 4 MiB L2), so all `nparts` workgroups of one unit are given linear ids that are equal mod 8: they land on one
 // XCD and the unit's matrices are pulled from HBM once.  Launch with xcd_grid(n_ids, nparts) workgroups.
+// The unit of a launch slot from its 16-byte record (see SlotRec): one load, everything uniform.
+struct UnitRef { int u, m, row_off; size_t mat_off; };
+__device__ __forceinline__ UnitRef unit_ref(const SlotRec *__restrict__ rec, int slot) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    i4 r = *reinterpret_cast<const i4 *>(rec + slot);
+    UnitRef x;
+    x.u = __builtin_amdgcn_readfirstlane(r.x);
+    x.m = __builtin_amdgcn_readfirstlane(r.y);
+    x.row_off = __builtin_amdgcn_readfirstlane(r.z);
+    x.mat_off = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(r.w) << 8;
+    return x;
+}
+
+// Diagnostic builds (-DGPRF_WGTRACE=<id>: 1 solve, 2 at, 3 mgrad, 4 / 5 the Cholesky's 512- / 256-register kernel): every workgroup of that kernel records when and where
+// it ran — (start, end) of the constant-rate counter, the HW_ID / XCC_ID registers — for scripts/gpu_wg_trace.py.
+struct WgTrace {
+#ifdef GPRF_WGTRACE
+    unsigned long long t0;
+    double *rec;
+    __device__ __forceinline__ WgTrace(const UnitTab &ut, const Pools &pl, int id) {
+        rec = nullptr;
+        if (id == GPRF_WGTRACE && threadIdx.x == 0 && (int)blockIdx.x < GPRF_WGTRACE_MAX)
+            rec = pl.dbg + (size_t)(ut.n_units > 1 ? ut.n_units : 1) * 8 + (size_t)blockIdx.x * 4;
+        t0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void done(int tag) {
+        if (rec) {
+            unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            rec[0] = (double)t0;
+            rec[1] = (double)__builtin_amdgcn_s_memrealtime();
+            rec[2] = (double)(((unsigned long long)(xcc & 0xf) << 32) | hw);
+            rec[3] = (double)tag;
+        }
+    }
+#else
+    __device__ __forceinline__ WgTrace(const UnitTab &, const Pools &, int) {}
+    __device__ __forceinline__ void done(int) {}
+#endif
+};
+
 __device__ __forceinline__ bool xcd_map(int linear, int n_ids, int nparts, int *slot, int *part) {
     int grp = linear / (8 * nparts);
     int rem = linear - grp * (8 * nparts);
@@ -280,8 +321,9 @@ template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) {
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
     __shared__ double xr[64 * XS];
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
+    int u = ur.u;
+    int m = ur.m;
     int mp = pad16(m);
     int nt = (mp + 63) >> 6;
     int pidx = blockIdx.x;
@@ -290,7 +332,7 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
     while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
     int tj = ti + rem;
     int r0 = ti * 64, c0 = tj * 64;
-    const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XS;
+    const double *Xu = pl.Xu + (size_t)ur.row_off * XS;
     int t = threadIdx.x;
 #pragma unroll
     for (int e = t; e < 64 * XS; e += 256) {
@@ -303,7 +345,7 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) 
 #pragma unroll
     for (int d = 0; d < XN; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XS + d] : 0.0;
     __syncthreads();
-    double *U = pl.K + ut.mat_off[u];     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
+    double *U = pl.K + ur.mat_off;     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
     double diag_add = kp.nv + ut.jitter[u];
     int rbase = t >> 6;
 #pragma unroll 4
@@ -498,8 +540,9 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[POTRF_WAVES];
-    int u = ut.ids[blockIdx.x];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, blockIdx.x);
+    int u = ur.u;
+    int m = ur.m;
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     if (m == 0) {
@@ -514,9 +557,9 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *Tt = rdt + 16;                // [16][17]  look-ahead tile, row-major
     double *dvals = Tt + 16 * 17;         // [mp]      diagonal of U
-    double *U = pl.U + ut.mat_off[u];
-    const double *Kp = pl.K + ut.mat_off[u];   // every tile is first read from the K pool (all of them in step 0)
-    double *V = pl.V + (size_t)ut.row_off[u] * 16;
+    double *U = pl.U + ur.mat_off;
+    const double *Kp = pl.K + ur.mat_off;   // every tile is first read from the K pool (all of them in step 0)
+    double *V = pl.V + (size_t)ur.row_off * 16;
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
 
@@ -777,6 +820,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[RW];
+#ifdef GPRF_WGTRACE
+    __shared__ double s_tr0;       // (WgTrace itself does not survive this kernel's register discipline)
+    if (threadIdx.x == 0) s_tr0 = (double)__builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef GPRF_PROFILE
     unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -785,24 +832,27 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // workgroup can only be scheduled on an EMPTY CU: waiting for one to drain behind the two-per-CU kernel's residents,
     // just to exit, would hold back this kernel's completion): they take units from the END of the small list (the
     // smallest ones; this instantiation handles every size), and the small-unit launch leaves those to them.
-    int u;
+    // (the record of this workgroup's most likely slot is loaded alongside the list lengths, not behind them)
+    UnitRef ur;
     if (which == 0) {
-        u = ut.ids[blockIdx.x];
+        ur = unit_ref(ut.srec, blockIdx.x);
     } else {
+        int bid = blockIdx.x;
+        ur = unit_ref(which == 1 ? ut.big_rec : ut.small_rec, bid);
         int nb = ut.ctl[CTL_NBIG], ns = ut.ctl[CTL_NSMALL];
         int surplus = ut.grid_big > nb ? ut.grid_big - nb : 0;
         if (surplus > ns) surplus = ns;
-        int bid = blockIdx.x;
         if (which == 1) {
-            if (bid < nb) u = ut.big_list[bid];
-            else if (bid - nb < surplus) u = ut.small_list[ns - 1 - (bid - nb)];
-            else return;
+            if (bid >= nb) {
+                if (bid - nb < surplus) ur = unit_ref(ut.small_rec, ns - 1 - (bid - nb));
+                else return;
+            }
         } else {
             if (bid >= ns - surplus) return;
-            u = ut.small_list[bid];
         }
     }
-    int m = ut.m[u];
+    const int u = ur.u;
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     if (T > reg_maxT) return;             // k_potrf's units
     if (m == 0) {
@@ -823,9 +873,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *dvals = rdt + 16;             // [16 T]    diagonal of U
     double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
-    double *U = pl.U + ut.mat_off[u];
-    const double *Kp = pl.K + ut.mat_off[u];   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
-    double *V = pl.V + (size_t)ut.row_off[u] * 16;
+    double *U = pl.U + ur.mat_off;
+    const double *Kp = pl.K + ur.mat_off;   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
+    double *V = pl.V + (size_t)ur.row_off * 16;
     if (threadIdx.x == 0) s_fail = 0;
     unsigned glane = (unsigned)(lg * mp + lr);
     int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
@@ -910,7 +960,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
     };
     if constexpr (GEN) {
-        const double *Xu = pl.Xu + (size_t)ut.row_off[u] * XPAD;
+        const double *Xu = pl.Xu + (size_t)ur.row_off * XPAD;
         for (int e = threadIdx.x; e < mp * XPAD; e += RW * 64) xs[e] = Xu[e];
         __syncthreads();
     }
@@ -1095,7 +1145,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // reads of a row issued before its stores.  Nothing reads it back before the epilogue, so no barrier waits
     // for these stores.
     auto copy_panel = [&](int jp, int a0, int da) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
         const double *Pj = P0 + (jp & (NPB - 1)) * 16 * ldp;
         // two columns per lane (16-byte LDS reads and global stores: the copy is instruction-issue bound); the
         // panel starts at a multiple of 16 columns and mp <= 256, so two 128-column chunks cover it
@@ -1324,6 +1373,16 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         pl.dbg[(size_t)u * 8 + 6] = (double)(__builtin_amdgcn_s_memtime() - t_loopend);
     }
 #endif
+#ifdef GPRF_WGTRACE
+    if ((WPS == 1 ? 4 : 5) == GPRF_WGTRACE && threadIdx.x == 0 && (int)blockIdx.x < GPRF_WGTRACE_MAX) {
+        double *rec = pl.dbg + (size_t)(ut.n_units > 1 ? ut.n_units : 1) * 8 + (size_t)blockIdx.x * 4;
+        unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        rec[0] = s_tr0;
+        rec[1] = (double)__builtin_amdgcn_s_memrealtime();
+        rec[2] = (double)(((unsigned long long)(xcc & 0xf) << 32) | hw);
+        rec[3] = (double)(T * 8 + which);
+    }
+#endif
 }
 
 // the two kernels around the body (an attribute cannot depend on a template parameter): one workgroup per CU with 512
@@ -1351,8 +1410,9 @@ constexpr int SOLVE_SLOTS = MAX_T / SOLVE_WAVES;  // 8
 __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl, int dy) {
     __shared__ double Wr[2][256];
     __shared__ double zred[SOLVE_WAVES];
-    int u = ut.ids[blockIdx.y];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
+    int u = ur.u;
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int bx = blockIdx.x;
     bool is_y = bx >= ut.max_T;
@@ -1360,14 +1420,14 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
     if (!is_y && cb >= T) return;
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
+    size_t roff = ur.row_off;
     if (T == 0) {
         if (is_y && threadIdx.x == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
         return;
     }
-    const double *U = pl.U + ut.mat_off[u];
+    const double *U = pl.U + ur.mat_off;
     const double *V = pl.V + roff * 16;
-    double *W = pl.W + ut.mat_off[u];
+    double *W = pl.W + ur.mat_off;
     double *Z = pl.Z + roff * YPAD;
     const int32_t *upt = ut.upt + roff;
     int r0 = is_y ? 0 : cb;
@@ -1458,15 +1518,22 @@ constexpr int SOLVE_PANEL_MAXT = 28;  // largest k_solve_panel instantiation (ac
 // (accumulator register q = rows 4q+lg), so the right-looking updates chain through registers.
 template <int MAXT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, int dy) {
-    constexpr int LDP = 16 * MAXT + 16;          // (LDP/16) odd: lane groups 32 banks apart
-    constexpr int NCH = (16 * MAXT + 63) / 64;
-    __shared__ double panel[2][16 * LDP];
+    // panel columns are stored RELATIVE to the first column right of the diagonal tile (16(r+1)): a step loads and
+    // keeps only what its updates read.  (LDP/16) odd: lane groups 32 banks apart
+    constexpr int LDP = 16 * ((MAXT - 1) | 1);
+    constexpr int NCH = (16 * (MAXT - 1) + 127) / 128;
+    __shared__ __attribute__((aligned(16))) double panel[2][16 * LDP];
     __shared__ double Vl[2][256];
     int slot_, part_;
     int nI = (ut.max_T + 3) >> 2;                // parts 0..nI-1: identity column blocks 4p+wave; part nI: Y blocks
+    WgTrace trace(ut, pl, 1);
+#ifdef GPRF_PROFILE
+    unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
+#endif
     if (!xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_)) return;
-    int u = ut.ids[slot_];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, slot_);
+    int u = ur.u;
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int tid = threadIdx.x;
     int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
@@ -1474,7 +1541,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     bool is_y = part_ == nI;
     int cb = is_y ? wave : (part_ * 4 + wave);
     bool live = is_y || (cb < T);                // dead waves still stage panels and hit the barriers
-    size_t roff = ut.row_off[u];
+    size_t roff = ur.row_off;
     if (T == 0) {
         if (live && is_y && lane == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
         return;
@@ -1482,9 +1549,9 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     // first row any wave of this workgroup needs
     int rmin = is_y ? 0 : part_ * 4;
     if (rmin >= T) return;                        // whole workgroup beyond this unit's columns (uniform)
-    const double *__restrict__ U = pl.U + ut.mat_off[u];
+    const double *__restrict__ U = pl.U + ur.mat_off;
     const double *__restrict__ V = pl.V + roff * 16;
-    double *__restrict__ W = pl.W + ut.mat_off[u];
+    double *__restrict__ W = pl.W + ur.mat_off;
     double *__restrict__ Z = pl.Z + roff * YPAD;
     const double *__restrict__ Yg = pl.Y;
     int r0 = is_y ? 0 : cb;
@@ -1494,53 +1561,76 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     // fill half of the CU's LDS exactly, and one more kilobyte would halve the occupancy)
     int32_t *s_upt = reinterpret_cast<int32_t *>(&panel[1][0]);
     if (is_y) {
-        for (int e = tid; e < mp; e += 256) s_upt[e] = e < m ? ut.upt[roff + e] : -1;
+        // (every tile of the instantiation; a lane's four rows lg + 4q of a tile next to each other: one 16-byte read)
+        for (int e = tid; e < 16 * MAXT; e += 256)
+            s_upt[(e & ~15) + 4 * (e & 3) + ((e >> 2) & 3)] = e < m ? ut.upt[roff + e] : -1;
         __syncthreads();
     }
 
     // (static_for, not "#pragma unroll": the optimizer gives up on the 28-tile instantiation's loops and the
     // accumulators would land in scratch)
     d4 acc[MAXT];
-    static_for<0, MAXT>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
+    if (is_y) {
+        // Y[unit rows], zero padded: branch-free per element (an invalid row / column loads Y[0] and is masked), so that the
+        // table reads and the gather loads of all tiles are issued back to back instead of one round trip at a time
+        int col = 16 * cb + lr;
+        bool colok = col < dy;
+        // (no "r < T" branch either: rows beyond the unit read -1 from the table)
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        i4 pts[MAXT];
+        static_for<0, MAXT>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            pts[r] = *reinterpret_cast<const i4 *>(s_upt + 16 * r + 4 * lg);
+        });
+        static_for<0, MAXT>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double v = 0.0;
-            if (live && r >= r0 && r < T) {
-                if (is_y) {
-                    int row = 16 * r + lg + 4 * q, col = 16 * cb + lr;     // Y[unit rows]: gathered here, zero padded
-                    int pt = s_upt[row];
-                    if (pt >= 0 && col < dy) v = Yg[(size_t)pt * dy + col];
-                } else {
-                    v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
-                }
+            for (int q = 0; q < 4; ++q) {
+                int pt = pts[r][q];
+                bool ok = pt >= 0 && colok;
+                double v = Yg[ok ? (size_t)pt * dy + col : (size_t)0];     // (32-bit offsets measured SLOWER: 105 vs 89 us)
+                acc[r][q] = ok ? v : 0.0;
             }
-            acc[r][q] = v;
-        }
-    });
-    // staging registers: wave w carries rows 4w..4w+3 of the panel, NCH column chunks of 64, plus one V entry
-    double pre[4][NCH], prev;
-    // scalar row base + lane offset + immediate (no VALU address arithmetic per load); lanes left of the diagonal tile
-    // or right of mp load nothing (the kernel is HBM-bound: unpredicated loads cost 15 % more time)
-    auto fetch = [&](int r) {
+        });
+    } else {
+        static_for<0, MAXT>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            int col = 64 * k + lane;
-            bool ok = col >= 16 * (r + 1) && col < mp;
+            for (int q = 0; q < 4; ++q) acc[r][q] = (live && r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
+        });
+    }
+    // staging registers: wave w carries rows 4w..4w+3 of the panel, chunks of 128 columns (two per lane: 16-byte loads
+    // and LDS writes), plus one V entry.  Scalar row base + lane offset; a chunk beyond the unit's last column is
+    // skipped by a wave-uniform branch, lanes beyond it load nothing (unpredicated loads cost 15 % more time)
+    d2 pre[4][NCH];
+    double prev;
+    auto fetch = [&](int r, auto nchc) {
+        constexpr int nch = decltype(nchc)::value;
+        int ncols = mp - 16 * (r + 1);
+        const double *Ur = U + (size_t)(16 * r + 4 * wave) * mp + 16 * (r + 1) + 2 * (unsigned)lane;   // wave-uniform + lane
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const double *Ur = U + (size_t)(16 * r + 4 * wave + rr) * mp;      // wave-uniform
-                pre[rr][k] = ok ? Ur[64 * k + (unsigned)lane] : 0.0;
+        for (int k = 0; k < nch; ++k) {
+            if (128 * k < ncols) {                                                     // uniform
+                bool ok = 128 * k + 2 * lane < ncols;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    pre[rr][k] = ok ? *reinterpret_cast<const d2 *>(Ur + (size_t)rr * mp + 128 * k) : d2{0.0, 0.0};
             }
         }
         prev = V[(size_t)r * 256 + tid];
     };
-    fetch(rmin);
+    fetch(rmin, std::integral_constant<int, NCH>{});
     double zz = 0.0;
 #ifdef GPRF_PROFILE
     // GPRF_SOLVE_STAMPS build: wave 0 of the Y workgroup: cycles in [stage | barrier | fetch | solve tile | updates]
+    // (-DGPRF_SOLVE_STAMP_PART=p: the identity workgroup p instead; slots 6 / 7: cycles before the step loop / after it)
     unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#ifdef GPRF_SOLVE_STAMP_PART
+    bool stamp = part_ == GPRF_SOLVE_STAMP_PART && wave == 0;
+#else
     bool stamp = is_y && wave == 0;
+#endif
+    unsigned long long t_pro = tprev - t_kernel0, t_loop_end = 0;
 #define GPRF_SST(k)                                                       \
     if (stamp) {                                                          \
         unsigned long long tn = __builtin_amdgcn_s_memtime();             \
@@ -1554,19 +1644,23 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
         constexpr int r = decltype(rc)::value;
         if (r >= rmin && r < T) {                 // uniform over the workgroup
             double *buf = panel[r & 1];
+            constexpr int nch_r = (16 * (MAXT - 1 - r) + 127) / 128;          // chunks a unit of MAXT tiles needs at this step
+            {
+                int ncols = mp - 16 * (r + 1);
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                int col = 64 * k + lane;
-                if (col < LDP) {
+                for (int k = 0; k < nch_r; ++k) {
+                    if (128 * k + 2 * lane < ncols) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) buf[(4 * wave + rr) * LDP + col] = pre[rr][k];
+                        for (int rr = 0; rr < 4; ++rr)
+                            *reinterpret_cast<d2 *>(buf + (4 * wave + rr) * LDP + 128 * k + 2 * lane) = pre[rr][k];
+                    }
                 }
             }
             Vl[r & 1][tid] = prev;
             GPRF_SST(0)
             lds_barrier();                        // LDS only: no wait for the W / Z stores of the step before
             GPRF_SST(1)
-            if (r + 1 < T) fetch(r + 1);
+            if (r + 1 < T) fetch(r + 1, std::integral_constant<int, (16 * (MAXT - 2 - r) + 127) / 128>{});
             GPRF_SST(2)
             if (live && r >= r0) {
                 const double *vl = Vl[r & 1] + lg * 16 + lr;
@@ -1591,7 +1685,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
                     constexpr int r2 = decltype(r2c)::value;
                     if (r2 < T) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * r2], w[s], acc[r2]);
+                        for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * (r2 - r - 1)], w[s], acc[r2]);
                     }
                 });
                 GPRF_SST(4)
@@ -1599,16 +1693,26 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
         }
     });
 #ifdef GPRF_PROFILE
-    if (stamp && lane == 0) {
-        for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
-        pl.dbg[(size_t)u * 8 + 5] = (double)T;
-    }
+    t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 #undef GPRF_SST
     if (live && is_y) {
         for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
         if (lane == 0) pl.zzpart[(size_t)u * 4 + cb] = zz;
     }
+#ifdef GPRF_PROFILE
+    if (stamp) {
+        __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0): the W / Z stores have left
+        unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            for (int k = 0; k < 5; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
+            pl.dbg[(size_t)u * 8 + 5] = (double)T;
+            pl.dbg[(size_t)u * 8 + 6] = (double)t_pro;
+            pl.dbg[(size_t)u * 8 + 7] = (double)(t_end - t_loop_end);
+        }
+    }
+#endif
+    trace.done(T * 8 + part_);
 }
 
 // k_at_wide: the throughput form of k_at (many units per CU): one workgroup per 16 column tiles of the unit; wave w owns the column tiles
@@ -1617,16 +1721,17 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
 __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
     int slot_, part_;
+    WgTrace trace(ut, pl, 2);
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
-    int u = ut.ids[slot_];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, slot_);
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int I0 = 16 * part_;
     if (I0 >= T) return;
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    size_t roff = ur.row_off;
+    const double *__restrict__ W = pl.W + ur.mat_off;
     const double *__restrict__ Z = pl.Z + roff * YPAD;
     double *__restrict__ At = pl.At + roff * YPAD;
     d4 acc[4][4];   // [owned column tile][16-row block of At]
@@ -1668,6 +1773,7 @@ __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
                 for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[o][c][q];
         }
     }
+    trace.done(T * 8 + part_);
 }
 
 // k_at: At = Z^T W with one workgroup per AT_TILES column tiles of the unit; wave w owns the column tiles
@@ -1679,16 +1785,17 @@ constexpr int AT_TILES = 8;    // column tiles of At per workgroup (two per wave
 
 __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     int slot_, part_;
+    WgTrace trace(ut, pl, 2);
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES, &slot_, &part_)) return;
-    int u = ut.ids[slot_];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, slot_);
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int I0 = AT_TILES * part_;
     if (I0 >= T) return;
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    size_t roff = ur.row_off;
+    const double *__restrict__ W = pl.W + ur.mat_off;
     const double *__restrict__ Z = pl.Z + roff * YPAD;
     double *__restrict__ At = pl.At + roff * YPAD;
     constexpr int NO = AT_TILES / 4;
@@ -1749,6 +1856,7 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
                 for (int q = 0; q < 4; ++q) At[(size_t)(16 * c + lg + 4 * q) * mp + 16 * I + lr] = acc[o][c][q];
         }
     }
+    trace.done(T * 8 + part_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1796,9 +1904,11 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     __shared__ double xsh[128 * PtRec<DIST>::NREG];
     int TBm = (ut.max_T + 3) >> 2;
     int slot, bp;
+    WgTrace trace(ut, pl, 3);
     if (!xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp)) return;
-    int u = ut.ids[slot];
-    int m = ut.m[u];
+    const UnitRef ur = unit_ref(ut.srec, slot);
+    int u = ur.u;
+    int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int TB = (T + 3) >> 2;
     // block pair index -> (JB, IB >= JB), enumerated over the launch-wide TBm
@@ -1811,8 +1921,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     // then uniform for the compiler too and turns into scalar branches instead of EXEC masking
     int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ut.row_off[u];
-    const double *__restrict__ W = pl.W + ut.mat_off[u];
+    size_t roff = ur.row_off;
+    const double *__restrict__ W = pl.W + ur.mat_off;
     const double *__restrict__ At = pl.At + roff * YPAD;
     int J0 = 4 * JB;
     // Which of the block's four row tiles this wave owns rotates with the workgroup: in a diagonal block pair row tile
@@ -1955,7 +2065,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     GPRF_MST(0)
     double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
     double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
-    const double *__restrict__ Kp = pl.K + ut.mat_off[u];
+    const double *__restrict__ Kp = pl.K + ur.mat_off;
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
     const int tbs = TBm;                               // stride of the per-block partials
     // FAST instantiation (SE kernel, at most two input dimensions, no hyper-parameter gradient — the north-star
@@ -2198,6 +2308,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
         int pidx = JB * TB - (JB * (JB - 1)) / 2 + (IB - JB);       // block pair index within the unit
         pl.gcpart[((size_t)u * (TBm * (TBm + 1) / 2) + pidx) * GC_SLOTS + tid] = v;
     }
+    trace.done(T * 64 + IB * 8 + JB);
 }
 
 // gXu[row] = sum_{IB >= B} colpart[row][IB] + sum_{JB <= B} rowpart[row][JB],  B = the row's 64-point block
@@ -2568,7 +2679,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
     }
     // (the unit sizes stay in LDS for the second pass: every global round trip of this one-workgroup kernel is exposed)
     constexpr int M_LDS = 8192;
-    __shared__ int s_m[M_LDS];
+    __shared__ int s_m[M_LDS], s_ro[M_LDS];
+    __shared__ unsigned s_mo[M_LDS];
     if (t == 0) s_maxm = 0;
     __syncthreads();
     long long rows = 0, mat = 0;
@@ -2589,7 +2701,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
             bt.off_j[l] = mi;
             bt.row_off[l] = (int32_t)r0;
             bt.mat_off[l] = mat + b;
-            if (l < M_LDS) s_m[l] = m;
+            if (l < M_LDS) { s_m[l] = m; s_ro[l] = (int32_t)r0; s_mo[l] = (unsigned)((mat + b) >> 8); }
             atomicMax(&s_maxm, m);
         }
         rows += ta;
@@ -2599,29 +2711,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
     int maxm = s_maxm;
     int maxT = ((maxm + 15) & ~15) >> 4;
     bool over = rows > bt.cap_rows || mat > bt.cap_mat || maxT > bt.maxT_bound || maxm > MAX_MP;
-    // the Cholesky's two launch lists (units of more than small_maxT tiles one to a CU, the others two to a CU): a
-    // stable partition of the launch order by THIS partition's sizes
+    // the launch-slot records (SlotRec) in launch order, and the Cholesky's two launch lists (units of more than
+    // small_maxT tiles one to a CU, the others two to a CU): a stable partition of the launch order by THIS partition's
+    // sizes, as unit ids and as records
     long long nbig = 0;
-    if (bt.small_maxT > 0) {
-        for (int k0 = 0; k0 < bt.n_local; k0 += SCAN_THREADS) {
-            int k = k0 + t;
-            int u = 0;
-            long long big = 0, one = 0, tb_, to_;
-            if (k < bt.n_local) {
-                u = bt.ids[k];
-                int mu = u < M_LDS ? s_m[u] : bt.m[u];
-                big = ((mu + 15) >> 4) > bt.small_maxT ? 1 : 0;
-                one = 1;
-            }
+    for (int k0 = 0; k0 < bt.n_local; k0 += SCAN_THREADS) {
+        int k = k0 + t;
+        SlotRec r = {0, 0, 0, 0u};
+        long long big = 0, one = 0, tb_, to_;
+        if (k < bt.n_local) {
+            int u = bt.ids[k];
+            r.u = u;
+            r.m = over ? 0 : (u < M_LDS ? s_m[u] : bt.m[u]);
+            r.row_off = u < M_LDS ? s_ro[u] : bt.row_off[u];
+            r.mat256 = u < M_LDS ? s_mo[u] : (unsigned)(bt.mat_off[u] >> 8);
+            bt.srec[k] = r;
+            big = (bt.small_maxT > 0 && ((r.m + 15) >> 4) > bt.small_maxT) ? 1 : 0;
+            one = 1;
+        }
+        if (bt.small_maxT > 0) {
             long long isbig = big, pos = one;
             wg_exscan2(big, pos, sh, &tb_, &to_);
             if (k < bt.n_local) {
-                if (isbig) bt.big_list[nbig + big] = u;
-                else bt.small_list[(k0 - nbig) + (pos - big)] = u;
+                if (isbig) {
+                    bt.big_list[nbig + big] = r.u;
+                    bt.big_rec[nbig + big] = r;
+                } else {
+                    bt.small_list[(k0 - nbig) + (pos - big)] = r.u;
+                    bt.small_rec[(k0 - nbig) + (pos - big)] = r;
+                }
             }
             nbig += tb_;
         }
-        over = over || nbig > bt.grid_big || (bt.n_local - nbig) > bt.grid_small;
+    }
+    if (bt.small_maxT > 0 && !over && (nbig > bt.grid_big || (bt.n_local - nbig) > bt.grid_small)) {
+        over = true;      // a list outgrew its launch: like every other overflow, nothing of this build may be used
+        __syncthreads();
+        for (int l = t; l < bt.n_local; l += SCAN_THREADS) { bt.srec[l].m = 0; bt.big_rec[l].m = 0; bt.small_rec[l].m = 0; }
     }
     if (over)
         for (int l = t; l < bt.n_local; l += SCAN_THREADS) { bt.m[l] = 0; bt.row_off[l] = 0; bt.mat_off[l] = 0; bt.off_j[l] = 0; }

@@ -19,4 +19,5 @@ for T in (7, 13, 15, 16):
     sel = rows[rows[:, 5] == T]
     if len(sel):
         m = sel[:, :5].mean(axis=0) / T
-        print("T=%d units=%d cycles/step:" % (T, len(sel)), " ".join("%s %.0f" % (a, v) for a, v in zip(["stage", "barrier", "fetch", "solve", "update"], m)), " total/step %.0f  total %.0f" % (m.sum(), m.sum() * T))
+        print("T=%d units=%d cycles/step:" % (T, len(sel)), " ".join("%s %.0f" % (a, v) for a, v in zip(["stage", "barrier", "fetch", "solve", "update"], m)), " total/step %.0f  total %.0f" % (m.sum(), m.sum() * T),
+              " | before the loop %.0f  after it %.0f" % (sel[:, 6].mean(), sel[:, 7].mean()))
