@@ -1531,6 +1531,8 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
     if (!xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_)) return;
+    // the Y workgroup (every step, a gather in front) is the longest of a unit: it is dispatched first
+    part_ = part_ == 0 ? nI : part_ - 1;
     const UnitRef ur = unit_ref(ut.srec, slot_);
     int u = ur.u;
     int m = ur.m;
@@ -2918,6 +2920,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                         (void)hipStreamWaitEvent(s2, side.ev_fork, 0);
                     }
                 }
+                // (the large-unit kernel must go FIRST and on the main queue: launched behind the two-per-CU kernel it waits
+                // for whole CUs to drain — measured: stage 178-264 us instead of 121)
                 // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
                 // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
                 // the grids follow the list lengths of the last synchronised partition with a little slack)
