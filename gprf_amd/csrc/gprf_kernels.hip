@@ -1601,22 +1601,41 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
             for (int q = 0; q < 4; ++q) acc[r][q] = (live && r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
         });
     }
-    // staging registers: wave w carries rows 4w..4w+3 of the panel, chunks of 128 columns (two per lane: 16-byte loads
-    // and LDS writes), plus one V entry.  Scalar row base + lane offset; a chunk beyond the unit's last column is
-    // skipped by a wave-uniform branch, lanes beyond it load nothing (unpredicated loads cost 15 % more time)
-    d2 pre[4][NCH];
+    // wave w carries rows 4w..4w+3 of the panel in chunks of 128 columns (two per lane: 16 bytes).  Scalar row base + lane
+    // offset; a chunk beyond the unit's last column is skipped by a wave-uniform branch, lanes beyond it load nothing
+    // (unpredicated loads cost 15 % more time).
+    // GPRF_SOLVE_GLDS (default): the chunks go from memory straight into the panel buffer of their step
+    // (global_load_lds_dwordx4: 64 lanes x 16 bytes land as one contiguous kilobyte = 128 columns of one row, exactly
+    // the panel's layout) — no staging registers, no ds_write pass in front of the barrier; panel r + 1 is requested
+    // right after barrier r into the buffer nobody reads any more, and waited for (vmcnt) in front of barrier r + 1.
+#ifndef GPRF_SOLVE_GLDS
+#define GPRF_SOLVE_GLDS 1
+#endif
+    constexpr bool GLDS = GPRF_SOLVE_GLDS != 0;
+    d2 pre[4][GLDS ? 1 : NCH];
     double prev;
     auto fetch = [&](int r, auto nchc) {
         constexpr int nch = decltype(nchc)::value;
         int ncols = mp - 16 * (r + 1);
         const double *Ur = U + (size_t)(16 * r + 4 * wave) * mp + 16 * (r + 1) + 2 * (unsigned)lane;   // wave-uniform + lane
+        double *dst = panel[r & 1] + (4 * wave) * LDP;                                                  // wave-uniform
 #pragma unroll
         for (int k = 0; k < nch; ++k) {
             if (128 * k < ncols) {                                                     // uniform
                 bool ok = 128 * k + 2 * lane < ncols;
+                if constexpr (GLDS) {
+                    if (ok) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    pre[rr][k] = ok ? *reinterpret_cast<const d2 *>(Ur + (size_t)rr * mp + 128 * k) : d2{0.0, 0.0};
+                        for (int rr = 0; rr < 4; ++rr)
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void *)(Ur + (size_t)rr * mp + 128 * k),
+                                (__attribute__((address_space(3))) void *)(dst + rr * LDP + 128 * k), 16, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        pre[rr][k] = ok ? *reinterpret_cast<const d2 *>(Ur + (size_t)rr * mp + 128 * k) : d2{0.0, 0.0};
+                }
             }
         }
         prev = V[(size_t)r * 256 + tid];
@@ -1647,7 +1666,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
         if (r >= rmin && r < T) {                 // uniform over the workgroup
             double *buf = panel[r & 1];
             constexpr int nch_r = (16 * (MAXT - 1 - r) + 127) / 128;          // chunks a unit of MAXT tiles needs at this step
-            {
+            if constexpr (!GLDS) {
                 int ncols = mp - 16 * (r + 1);
 #pragma unroll
                 for (int k = 0; k < nch_r; ++k) {
@@ -1658,9 +1677,11 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
                     }
                 }
             }
+            (void)nch_r;
             Vl[r & 1][tid] = prev;
+            if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's panel has landed
             GPRF_SST(0)
-            lds_barrier();                        // LDS only: no wait for the W / Z stores of the step before
+            lds_barrier();                        // LDS only (register staging: no wait for the W / Z stores of the step before)
             GPRF_SST(1)
             if (r + 1 < T) fetch(r + 1, std::integral_constant<int, (16 * (MAXT - 2 - r) + 127) / 128>{});
             GPRF_SST(2)
@@ -2014,6 +2035,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
 #else
 #define GPRF_SST2(k)
 #endif
+    // (chunks by global_load_lds straight into LDS — no staging registers, but only ONE chunk ahead with two LDS buffers,
+    // and a third does not fit four workgroups per CU — measured slower: 118 vs 111 us)
     auto step = [&](int c, double (&pre)[8], bool refill_even) {
 #ifdef GPRF_MGRAD_FINE
         tsp = __builtin_amdgcn_s_memtime();
