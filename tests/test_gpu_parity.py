@@ -571,3 +571,38 @@ def test_cholesky_launch_lists_follow_the_partition():
         assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
         fresh.close()
     g.close()
+
+
+def test_more_units_than_the_table_build_keeps_in_lds():
+    """k_build keeps the unit sizes / offsets of the first 8192 units in LDS for its second pass (launch-slot records,
+    Cholesky lists) and reads the rest back from global memory.  A partition of tiny blocks with more than 8192 units
+    takes that second path; its result must be the sum of two shards of the same problem, each of which stays below
+    8192 local units (first path), and the device-built tables must equal an uploaded host partition's."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(77)
+    n = 9000
+    X = rng.rand(n, 2)
+    Y = rng.randn(n, 3)
+    b = Blocker(grid_centers(2800))
+    nb = b.neighbors()
+    cov = GPCov([1.0], [0.02, 0.02], "euclidean", "se")
+    full = GPRF(X, Y, b.block_clusters, cov, 0.05, neighbors=nb)
+    ref = full.llgrad(grad_X=True, grad_cov=True)
+    nt, nl = full._ctx.num_units()
+    assert nl == nt and nt > 8192 + 1000, nt
+    acc = [0.0, np.zeros_like(ref[1]), np.zeros_like(ref[2])]
+    for rank in range(2):
+        g = GPRF(X, Y, b.block_clusters, cov, 0.05, neighbors=nb, shard=(rank, 2), reduce=False)
+        r = g.llgrad(grad_X=True, grad_cov=True)
+        assert 0 < g._ctx.num_units()[1] < 8192
+        acc[0] += r[0]; acc[1] += r[1]; acc[2] += r[2]
+        g.close()
+    assert np.isclose(acc[0], ref[0], rtol=1e-12)
+    assert np.allclose(acc[1], ref[1], rtol=0, atol=1e-11 * np.abs(ref[1]).max())
+    assert np.allclose(acc[2], ref[2], rtol=1e-10)
+    # ... and an uploaded host partition (tables forced through the same kernel, from block sizes) gives the same bits
+    host = GPRF(X, Y, None, cov, 0.05, block_idxs=b.block_clusters(X), neighbors=nb)
+    c = host.llgrad(grad_X=True, grad_cov=True)
+    assert ref[0] == c[0] and np.array_equal(ref[1], c[1]) and np.array_equal(ref[2], c[2])
+    full.close(); host.close()
