@@ -137,7 +137,7 @@ struct gprf_ctx {
     int tree_nodes = 0, tree_dim = 0, tree_wrap = 0;
     int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
     bool debug_mode = false;              // inside gprf_debug_run: also store the per-unit-row gradient slab (k_gx_finalize)
-    DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_gcpart, d_rowpart, d_colpart, d_dbg;
+    DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_usum, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_done;               // [0]: sequence number of the last finished host-io evaluation (k_done)
     int32_t done_seq = 0;
@@ -222,7 +222,7 @@ BuildTab make_build(gprf_ctx *c) {
 Pools make_pools(gprf_ctx *c) {
     Pools p;
     p.K = c->d_K.p; p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Y = c->d_Y.p; p.Z = c->d_Z.p;
-    p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p;
+    p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p; p.usum = c->d_usum.p;
     p.gcpart = c->d_gcpart.p; p.info = res_info(c); p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
     return p;
 }
@@ -270,6 +270,7 @@ int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
     size_t tbm = (size_t)std::max((maxT + 3) / 4, 1);      // 64-point blocks per edge of the largest local unit
     HIP_TRY(c, c->d_logdet.reserve(nl1));
     HIP_TRY(c, c->d_zzpart.reserve(nl1 * 4));
+    HIP_TRY(c, c->d_usum.reserve(nl1 * 8));
 #ifdef GPRF_WGTRACE
     HIP_TRY(c, c->d_dbg.reserve(nl1 * 8 + 4 * GPRF_WGTRACE_MAX));     // + one (start, end, hw id, block) record per workgroup
 #else
@@ -618,10 +619,10 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     if (do_grad) {
         launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);
-        launch_gx_finalize(ut, pl, s);
+        launch_gx_finalize(ut, pl, kp, want_gc, s);
     }
     mark();
-    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, s);
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, s);
     mark();
     HIP_TRY(c, hipGetLastError());
     // control words, unit status, block sizes -> pinned host: one download (or the assembly kernel's mirror)
@@ -829,7 +830,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
     c->d_tleaf.release();
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();
-    c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release();
+    c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release(); c->d_usum.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release();
     c->h_X.release(); c->h_out.release(); c->h_done.release();
     if (c->ev_valid)

@@ -118,6 +118,7 @@ struct Pools {
     double *colpart;  // k_mgrad: per padded row, TBm x XPAD partial column sums (one per row block IB >= its block)
     double *logdet;   // per unit
     double *zzpart;   // per unit x 4 : partial sums of ||Z||_F^2 per Y column block
+    double *usum;     // per unit x 8 : the unit's weighted terms of ll and gradC (k_gx_finalize -> k_assemble)
     double *gcpart;   // per unit x TBm (TBm + 1) / 2 block pairs x GC_SLOTS,  TBm = ceil(max_T / 4)
     int32_t *info;    // per unit: 0 ok, k>0 = non-positive pivot at row k-1
     double *dbg;      // per unit x 8: in-kernel cycle stamps of diagnostic builds (GPRF_POTRF_ABLATE & 16)
@@ -168,9 +169,9 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
                  bool have_K, hipStream_t s);
-void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s);
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
-                     int want_gx, int want_gc, double *out, hipStream_t s);
+                     int want_gx, int want_gc, double *out, int usum_ok, hipStream_t s);
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s);
 // threshold neighbour discovery: keep[c] = max |k| / sv over candidate block pair c > thr (early out unless want_max)
 void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const int64_t *blk_ptr, const int32_t *blk_pts,

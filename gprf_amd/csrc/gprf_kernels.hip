@@ -2338,12 +2338,38 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
 
 // gXu[row] = sum_{IB >= B} colpart[row][IB] + sum_{JB <= B} rowpart[row][JB],  B = the row's 64-point block
 // (fixed order -> bit-reproducible)
-__global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl, KParams kp, int want_gc) {
     int u = blockIdx.x;
-    int mp = pad16(ut.m[u]);
+    int m = ut.m[u];
+    int mp = pad16(m);
     int r0 = ut.row_off[u];
     int TB = ((mp >> 4) + 3) >> 2;
     int tbs = (ut.max_T + 3) >> 2;
+    // the unit's six terms of the final sums (weighted log-likelihood, weighted hyper-parameter gradient), by the last
+    // wave while the others fold the gradient slab: k_assemble's single summing workgroup then adds one row per unit
+    // instead of walking every unit's partials through chains of dependent loads (C4: 4033 units, 106 -> 20 us)
+    if (threadIdx.x >= 192) {
+        int t = threadIdx.x - 192;
+        if (t < 6) {
+            double w = ut.weight[u], v = 0.0;
+            if (m > 0) {
+                if (t == 0) {
+                    const double *zp = pl.zzpart + (size_t)u * 4;
+                    double zz = (zp[0] + zp[1]) + (zp[2] + zp[3]);
+                    double ll = -0.5 * zz - 0.5 * kp.dy * pl.logdet[u] - 0.5 * kp.dy * m * 1.8378770664093454836 /* log 2pi */;
+                    v = w * ll;
+                } else if (want_gc) {
+                    int nP = TB * (TB + 1) / 2;   // k_mgrad writes one partial per 64x64 block pair
+                    double g = 0.0;
+                    for (int P = 0; P < nP; ++P)
+                        g += pl.gcpart[((size_t)u * (tbs * (tbs + 1) / 2) + P) * GC_SLOTS + (t - 1)];
+                    // d/d nv: 1/2 tr(M); d/d sv: 1/2 sum M k / sv; d/d ls_t: 1/2 sum M dk/dls_t
+                    v = (t == 2) ? w * 0.5 * g / kp.sv : w * 0.5 * g;
+                }
+            }
+            pl.usum[(size_t)u * 8 + t] = v;
+        }
+    }
     for (int idx = threadIdx.x; idx < 4 * mp; idx += 256) {
         int local = idx >> 2, d = idx & 3;
         if (d == 3) continue;
@@ -2364,7 +2390,7 @@ __global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl) {
 // out = [ll | gradX (n x dx) | gradC (2 + ndfn) | overflow flag | units not PD]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
-                                                  int want_gx, int want_gc, double *out) {
+                                                  int want_gx, int want_gc, double *out, int usum_ok) {
     int dx = kp.dx;
     if (blockIdx.x == 0) {
         __shared__ double red[256][6];
@@ -2373,9 +2399,16 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
         if (threadIdx.x == 0) s_notpd = 0;
         __syncthreads();
         for (int u = threadIdx.x; u < ut.n_units; u += 256) {
+            if (pl.info[u] != 0) atomicAdd(&s_notpd, 1);
+            if (usum_ok) {                        // the terms k_gx_finalize left (same values, same order of addition)
+                const double *us = pl.usum + (size_t)u * 8;
+                acc[0] += us[0];
+                if (want_gc)
+                    for (int t = 1; t < 6; ++t) acc[t] += us[t];
+                continue;
+            }
             int m = ut.m[u];
             double w = ut.weight[u];
-            if (pl.info[u] != 0) atomicAdd(&s_notpd, 1);
             if (m > 0) {
                 const double *zp = pl.zzpart + (size_t)u * 4;
                 double zz = (zp[0] + zp[1]) + (zp[2] + zp[3]);
@@ -2881,7 +2914,11 @@ constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 poi
 // launch takes the register-resident kernel (SE kernel only).  The caller then skips k_fill and tells k_mgrad.
 static bool potrf_use_reg(const UnitTab &ut) {
     const char *rg = getenv("GPRF_POTRF_REG");
-    return (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : ut.n_ids <= 4 * device_cus();
+    // (round 1's rule "at most 4 units per CU, else the generic two-per-CU kernel" predates the two-per-CU register
+    // instantiation: with it the register path also wins at C4's 4033 units — no K pool to fill and read back:
+    // fill + Cholesky 1081 -> 716 us, the evaluation 3.05 -> 2.80 ms)
+    (void)ut;
+    return (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : true;
 }
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
@@ -2913,8 +2950,15 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
         if (gen && ut.max_T <= reg_maxT) {
             lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
-            static const bool serial = [] { const char *e = getenv("GPRF_POTRF_DUAL"); return e && e[0] == '2'; }();
-            if (serial) s2 = s;      // diagnostic: the two instantiations one after the other (standalone durations)
+            // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the
+            // profiler then serialises the dispatches of ALL queues, and the stream-memory-operation wait that joins the two
+            // queues in front of the solve would never see its value written (observed: the run hangs)
+            static const bool serial = [] {
+                const char *e = getenv("GPRF_POTRF_DUAL");
+                const char *c = getenv("ROCPROF_COUNTER_COLLECTION");
+                return (e && e[0] == '2') || (c && c[0] && c[0] != '0' && c[0] != 'F' && c[0] != 'f');
+            }();
+            if (serial) s2 = s;      // the two instantiations one after the other on the main queue
             const bool dual = potrf_dual_enabled();
             if (dual && s2 && ut.max_T > POTRF_SMALL_MAXT) {
                 // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
@@ -3021,9 +3065,9 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
         hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
 }
 
-void launch_gx_finalize(const UnitTab &ut, const Pools &p, hipStream_t s) {
+void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s) {
     if (ut.n_units == 0) return;
-    hipLaunchKernelGGL(k_gx_finalize, dim3(ut.n_units), dim3(256), 0, s, ut, p);
+    hipLaunchKernelGGL(k_gx_finalize, dim3(ut.n_units), dim3(256), 0, s, ut, p, kp, want_gc);
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
@@ -3154,9 +3198,9 @@ __global__ void k_done(int32_t *flag, int32_t seq) {
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_done, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
-                     int want_gx, int want_gc, double *out, hipStream_t s) {
+                     int want_gx, int want_gc, double *out, int usum_ok, hipStream_t s) {
     int blocks = 1 + (n + 31) / 32;
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out, usum_ok);
 }
 
 }  // namespace gprf
