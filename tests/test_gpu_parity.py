@@ -1,10 +1,14 @@
 """Parity of the HIP path (through the C ABI / gprf_amd.GPRF) against the oracle and the committed golden
 vectors.  Floating point (fp64) throughout; tolerances are stated per test.  North-star tolerance:
 gradient max-abs error < 1e-8 on the n=10000 configuration (tests/test_gpu_northstar.py)."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import load_golden, blocks_from_csr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -606,3 +610,38 @@ def test_more_units_than_the_table_build_keeps_in_lds():
     c = host.llgrad(grad_X=True, grad_cov=True)
     assert ref[0] == c[0] and np.array_equal(ref[1], c[1]) and np.array_equal(ref[2], c[2])
     full.close(); host.close()
+
+
+def test_one_queue_cholesky_under_counter_collection_gives_the_same_bits():
+    """rocprofv3 --pmc serialises the dispatches of all queues; the stream-memory-operation join of the two Cholesky
+    queues would then never complete, so the library puts both instantiations on ONE queue when it sees
+    ROCPROF_COUNTER_COLLECTION (set by --pmc) or GPRF_POTRF_DUAL=2.  Same kernels, same units: the result must be bit
+    for bit the two-queue result (fresh processes: the switch is read once per process)."""
+    import subprocess, sys
+    code = r'''
+import numpy as np, hashlib
+from gprf_amd import Blocker, grid_centers, GPCov
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(12)
+n = 6000
+X = rng.rand(n, 2); Y = rng.randn(n, 5)
+b = Blocker(grid_centers(64))
+g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.06, 0.06], "euclidean", "se"), 0.01, neighbors=b.neighbors())
+ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+sz = np.array([len(v) for v in g.block_idxs]); nb = b.neighbors()
+big = sum(1 for (i, j) in nb if sz[i] + sz[j] > 208)
+print("RESULT", repr(float(ll)), hashlib.sha1(np.ascontiguousarray(gX).tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(gC).tobytes()).hexdigest(), big)
+g.close()
+'''
+    outs = []
+    for extra in ({}, {"ROCPROF_COUNTER_COLLECTION": "1"}, {"GPRF_POTRF_DUAL": "2"}):
+        env = dict(os.environ)
+        env.pop("ROCPROF_COUNTER_COLLECTION", None)
+        env.update(extra)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+        outs.append(line[1:])
+    assert int(outs[0][3]) > 0                      # the partition really has units of both size classes
+    assert outs[0] == outs[1] == outs[2]
