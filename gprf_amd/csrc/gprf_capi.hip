@@ -199,6 +199,7 @@ UnitTab make_tab(gprf_ctx *c) {
     t.big_list = c->d_big_list.p; t.small_list = c->d_small_list.p; t.ctl = c->d_res.p;
     t.srec = c->d_srec.p; t.big_rec = c->d_big_rec.p; t.small_rec = c->d_small_rec.p;
     t.grid_big = c->grid_big; t.grid_small = c->grid_small;
+    t.fork_flag = nullptr; t.fork_seq = 0;
     return t;
 }
 

@@ -53,6 +53,10 @@ struct UnitTab {
     const int32_t *big_list, *small_list;
     const int32_t *ctl;
     int grid_big, grid_small;   // workgroups the two lists are launched with (the build reports a list that is longer)
+    // fork of the two Cholesky queues: the first workgroup of the large-unit kernel stores fork_seq here as its first
+    // instruction; the side queue's small-unit kernel sits behind a stream wait for that value (nullptr: none)
+    uint32_t *fork_flag;
+    uint32_t fork_seq;
 };
 
 // What the device-side table build works from and leaves behind (all device pointers).
@@ -161,7 +165,7 @@ int potrf_small_maxT();         // ... units of at most this many tiles per edge
 struct SideQueue {
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint32_t *words = nullptr;      // [2] device words: fork, join
+    uint32_t *words = nullptr;      // [3] device words: fork, join, fork written by the large-unit kernel itself
     uint32_t seq = 0;               // value of this evaluation (monotonic)
 };
 void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side);

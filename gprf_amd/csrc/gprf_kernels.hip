@@ -832,6 +832,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // workgroup can only be scheduled on an EMPTY CU: waiting for one to drain behind the two-per-CU kernel's residents,
     // just to exit, would hold back this kernel's completion): they take units from the END of the small list (the
     // smallest ones; this instantiation handles every size), and the small-unit launch leaves those to them.
+    // fork of the two Cholesky queues (launch_potrf): this kernel has started, so everything in front of it on the main
+    // queue is complete — tell the side queue, whose small-unit kernel waits for this word
+    if (which == 1 && ut.fork_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(ut.fork_flag, ut.fork_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (the record of this workgroup's most likely slot is loaded alongside the list lengths, not behind them)
     UnitRef ur;
     if (which == 0) {
@@ -2975,10 +2979,18 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // both ways 177; fork by memory operation + join by event 181; fork by event + join by memory operation
                 // 121 (the write in front of the large-unit kernel holds that kernel back; the wait in front of the
                 // solve does not).  GPRF_SIDE_MODE = 0 / 1 / 2 / 3 selects them in that order (diagnostics).
-                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : 3; }();
+                // 4 (default): no fork command — the large-unit kernel's first workgroup writes the word the side queue
+                // waits for — + join by memory operation: stage 110 (the event fork costs 12 us, all of it in front of the
+                // small-unit kernel, which finishes last)
+                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : 4; }();
                 const bool fork_values = side.words && (side_mode == 1 || side_mode == 2);
-                const bool join_values = side.words && (side_mode == 1 || side_mode == 3);
-                if (s2 != s) {      // fork: the side queue starts when everything enqueued on s so far is done
+                const bool join_values = side.words && (side_mode == 1 || side_mode == 3 || side_mode == 4);
+                // mode 4: no fork command at all — the large-unit kernel's first workgroup writes the word the side queue
+                // waits for (only when that kernel is really launched)
+                const bool fork_kernel = side.words && side_mode == 4 && ut.grid_big > 0 && s2 != s;
+                UnitTab utb = ut;
+                if (fork_kernel) { utb.fork_flag = side.words + 2; utb.fork_seq = side.seq; }
+                if (s2 != s && !fork_kernel) {      // fork: the side queue starts when everything enqueued on s so far is done
                     if (fork_values) {
                         (void)hipStreamWriteValue32(s, side.words, side.seq, 0);
                         (void)hipStreamWaitValue32(s2, side.words, side.seq, hipStreamWaitValueGte, 0xffffffffu);
@@ -2994,7 +3006,16 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // the grids follow the list lengths of the last synchronised partition with a little slack)
                 if (ut.grid_big > 0)
                     hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
-                                       dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 1);
+                                       dim3(POTRF_REG_WAVES * 64), lds, s, utb, p, stamps, reg_maxT, kp, 1);
+                if (fork_kernel) {
+                    // (should that launch ever be refused, nothing would write the word the side queue waits for)
+                    if (hipPeekAtLastError() != hipSuccess) (void)hipStreamWriteValue32(s, side.words + 2, side.seq, 0);
+                    // The wait goes in BEHIND the kernel that satisfies it, in host order: HIP streams share a few
+                    // hardware queues, which drain in submission order — a wait submitted ahead of its writer blocks the
+                    // writer whenever the two streams land on the same hardware queue (observed: ten contexts enqueued
+                    // back to back hang).  Every wait in this file depends on something submitted earlier.
+                    (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+                }
                 if (ut.grid_small > 0)
                     hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.grid_small),
                                        dim3(POTRF_REG_WAVES * 64), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
