@@ -1144,6 +1144,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #ifdef GPRF_PROFILE
     unsigned long long t_loop = tprev;
 #endif
+#ifdef GPRF_WGTRACE
+    __shared__ double s_tr1, s_tr2;       // start / end of the step loop
+    if (threadIdx.x == 0) s_tr1 = (double)__builtin_amdgcn_s_memrealtime();
+#endif
     const int s_end = T >= 2 ? __builtin_amdgcn_readlane(shv, T - 2) : 0;
     // solved row panel jp (LDS buffer jp & 1) -> global U, rows a0, a0 + da, ...; coalesced along the row, the LDS
     // reads of a row issued before its stores.  Nothing reads it back before the epilogue, so no barrier waits
@@ -1341,6 +1345,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #ifdef GPRF_PROFILE
     unsigned long long t_loopend = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef GPRF_WGTRACE
+    if (threadIdx.x == 0) s_tr2 = (double)__builtin_amdgcn_s_memrealtime();
+#endif
     if (stamp && lane == 0) {
         for (int k = 0; k < 4; ++k) pl.dbg[(size_t)u * 8 + k] = (double)tacc[k];
         pl.dbg[(size_t)u * 8 + 4] = (double)T;
@@ -1384,7 +1391,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         rec[0] = s_tr0;
         rec[1] = (double)__builtin_amdgcn_s_memrealtime();
         rec[2] = (double)(((unsigned long long)(xcc & 0xf) << 32) | hw);
-        rec[3] = (double)(T * 8 + which);
+        // tag + 1000 * (ticks before the step loop) + 1e7 * (ticks inside it): scripts/gpu_wg_trace.py PHASES=1
+        rec[3] = (double)(T * 8 + which) + 1000.0 * (s_tr1 - s_tr0) + 1e7 * (s_tr2 - s_tr1);
     }
 #endif
 }

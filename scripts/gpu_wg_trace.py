@@ -23,6 +23,15 @@ ctx._check(ctx.lib.gprf_debug_fetch(ctx.h, 0, 11, _capi.dptr(out), out.size), "f
 rec = out.reshape(-1, 4)
 rec = rec[rec[:, 1] > 0]
 t0, t1, hw, tag = rec[:, 0], rec[:, 1], rec[:, 2].astype(np.int64), rec[:, 3].astype(np.int64)
+if kern in (4, 5):          # the Cholesky kernels pack (ticks before the step loop, ticks inside it) behind the tag
+    loop_ticks = tag // 10000000
+    pro_ticks = (tag % 10000000) // 1000
+    tag = tag % 1000
+    for tg in sorted(set(tag.tolist())):
+        sel = tag == tg
+        if sel.sum() >= 20:
+            print("  tag %4d: before the step loop %.0f ticks, the loop %.0f, after it %.0f (means, 10 ns ticks)"
+                  % (tg, pro_ticks[sel].mean(), loop_ticks[sel].mean(), ((t1 - t0)[sel] - pro_ticks[sel] - loop_ticks[sel]).mean()))
 xcc = hw >> 32
 if os.environ.get("PER_XCC"):          # counters that are not synchronised across the XCDs: align their first starts
     for x in set(xcc.tolist()):
