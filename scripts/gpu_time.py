@@ -11,7 +11,7 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20, tag=""):
     X = rng.rand(n, 2); Y = rng.randn(n, dy)
     b = Blocker(grid_centers(nb)); blocks = b.block_clusters(X); nbrs = b.neighbors() if pairs else []
     g = GPRF(X, Y, None, GPCov([1.0], [lscale, lscale], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs,
-             shard=(0, int(os.environ["WORLD"])) if os.environ.get("WORLD") else None)
+             shard=(0, int(os.environ["WORLD"])) if os.environ.get("WORLD") else None, reduce=False)
     if os.environ.get("RAW"):
         # ablation runs produce garbage (possibly NOT_PD): time the raw C-ABI call and ignore the status
         g._push_neighbors(nbrs)
@@ -40,5 +40,8 @@ def timing(n=10000, nb=100, dy=50, lscale=0.06, pairs=True, reps=20, tag=""):
     g.close()
 
 if __name__ == "__main__":
+    if os.environ.get("C4"):      # BASELINE configs[3]'s shape
+        timing(n=80000, nb=800, lscale=0.02, pairs=True, tag=os.environ.get("TAG", "C4"))
+        sys.exit(0)
     timing(pairs=True, tag=os.environ.get("TAG", ""))
     if os.environ.get("LOCAL"): timing(pairs=False, tag="local")
