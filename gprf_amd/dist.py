@@ -173,7 +173,7 @@ class DeviceEvaluator(object):
         """one evaluation + all-reduce + download, fully finished: -> (host vector, local status, local bad unit)"""
         torch, st = self.torch, self.stream
         with torch.cuda.stream(st):
-            self.g._ctx.eval_device(self.d_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream,
+            self.g._ctx.eval_device(self.h_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream,
                                     reblock=reblock)
             allreduce_sum_(self.d_out, self.group)
             self.h_out.copy_(self.d_out, non_blocking=True)
@@ -184,9 +184,9 @@ class DeviceEvaluator(object):
     def evaluate(self, X, grad_X=False, grad_cov=False, reblock=False):
         """-> (ll, gradX, gradC, reblocked) with jitchol's retry applied identically on every rank."""
         torch, st = self.torch, self.stream
-        with torch.cuda.stream(st):
-            self.h_X.numpy()[:] = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
-            self.d_X.copy_(self.h_X, non_blocking=True)
+        # X goes into pinned host memory and the kernels read it from there (the partition kernel, which runs first when
+        # re-blocking, leaves a copy in HBM for the others; without re-blocking only k_scatter_x reads it): no copy command
+        self.h_X.numpy()[:] = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
         g = self.g
         no = out_len(self.n, self.dx, self.ncov)
 

@@ -18,6 +18,12 @@ b = Blocker(grid_centers(100)); nbrs = b.neighbors()
 cov = GPCov([1.0], [0.06, 0.06], "euclidean", "se")
 Xs = [np.ascontiguousarray(X + 2e-4 * k * rng.randn(n, 2)) for k in range(10)]
 plain = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs)
+def rate(fn, N=500):
+    for k in range(30): fn(Xs[k % 10])
+    t0 = time.perf_counter()
+    for k in range(N): fn(Xs[k % 10])
+    return (time.perf_counter() - t0) / N * 1e6
+print("plain, before the sharded context exists: %.1f us" % rate(lambda Xk: (plain.update_X(Xk), plain.llgrad(grad_X=True))))
 shard = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs, shard=(0, 1))
 from gprf_amd import dist as gdist
 shard._dist_eval = gdist.DeviceEvaluator(shard)
