@@ -2103,7 +2103,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(&chunk[0][0]);      // [4 waves][64 columns][4]
     double (*gcred)[8] = reinterpret_cast<double (*)[8]>(&chunk[1][0]);            // [4 waves][8]
     const double *__restrict__ Kp = pl.K + ur.mat_off;
-    constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
+    constexpr int XN = PtRec<DIST>::NREG;
     const int tbs = TBm;                               // stride of the per-block partials
     // FAST instantiation (SE kernel, at most two input dimensions, no hyper-parameter gradient — the north-star
     // task): the third coordinate's terms and the theta sums are compiled out of the reductions, whose VALU volume
