@@ -4,7 +4,7 @@
 // Who builds what.  The STATIC tables depend on the neighbour list, the shard and the jitter only: unit -> (block i,
 // block j), Bethe weight, block -> units CSR, launch order; they are built here on the host (rebuild_static) and
 // uploaded in one staged copy.  Everything that depends on the PARTITION — unit sizes, row / matrix offsets, the unit
-// row -> point table, a point's position inside its block — is built on the device (k_unit_scan, k_place) from the
+// row -> point table, a point's position inside its block — is built on the device (k_build, k_scatter_x) from the
 // block of every point, which is either computed on the device too (k_assign / k_route: the re-blocking the
 // reference's drivers do before every evaluation, gprf.py:169-174) or uploaded (gprf_set_blocks).  An evaluation that
 // re-partitions therefore never returns to the host in the middle: one upload of X, one download of the result
@@ -240,7 +240,7 @@ KParams make_kparams(gprf_ctx *c) {
     return k;
 }
 
-// sizes / offsets of the local units as the device derives them (k_unit_scan), recomputed from the block sizes
+// sizes / offsets of the local units as the device derives them (k_build), recomputed from the block sizes
 void refresh_host_units(gprf_ctx *c) {
     const int nl = c->n_local;
     c->l_m.resize(nl); c->l_rowoff.resize(nl); c->l_matoff.resize(nl);
@@ -294,7 +294,7 @@ int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
 
 // Workspace capacities for the partitions to come.  Padded rows have a partition-independent bound (a point
 // appears once in every unit that contains its block); the matrix pools get headroom over the present partition and
-// the launch-wide tile bound is the present largest unit: k_unit_scan reports a partition that exceeds any of them,
+// the launch-wide tile bound is the present largest unit: k_build reports a partition that exceeds any of them,
 // the host grows them and repeats that one evaluation (run_checked).
 int size_workspace(gprf_ctx *c, int64_t min_rows, int64_t min_mat, int min_maxT) {
     std::vector<int> per_block((size_t)std::max(c->n_blocks, 1), 0);

@@ -24,7 +24,7 @@ struct KParams {
 };
 
 // Per-unit tables (device pointers), one entry per LOCAL unit.  m / row_off / mat_off / off_j / upt are written ON THE
-// DEVICE from the partition (k_unit_scan, k_place): nothing about a re-blocking returns to the host.
+// DEVICE from the partition (k_build, k_scatter_x): nothing about a re-blocking returns to the host.
 // One 16-byte record per launch slot: everything a workgroup needs to find its unit, in ONE load instead of the chain
 // ids[slot] -> m[u] -> row_off[u] -> mat_off[u] (four dependent memory round trips at the head of every workgroup of
 // every kernel: 12-17 k cycles before the first useful instruction, measured).  Written by k_build next to the tables.
@@ -64,7 +64,7 @@ struct BuildTab {
     int32_t *assign;         // [n] block of every point, -1 = in no block
     int32_t *posb;           // [n] position of the point inside its block
     int32_t *rank;           // [n] scratch: position among the points of the same block within its CHUNK-point chunk
-    int32_t *cnt;            // [n_chunks][n_blocks] points of a block per chunk -> (k_unit_scan) exclusive prefix over chunks
+    int32_t *cnt;            // [n_chunks][n_blocks] points of a block per chunk -> (k_build) exclusive prefix over chunks
     int32_t *bsize;          // [n_blocks] points per block
     const int32_t *unit_bi;  // [n_local] first block of the unit
     const int32_t *unit_bj;  // [n_local] second block, -1 for a unary unit
@@ -113,7 +113,7 @@ struct Pools {
     double *W;     // U^-T (lower triangular, row-major)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
     double *Xu;    // gathered unit coordinates per padded row: XPAD doubles (euclidean) or the 8-double half-angle
-                   // record of the lld distance (k_gather_x)
+                   // record of the lld distance (k_scatter_x)
     const double *Y;  // the outputs, n x dy row-major (gathered through upt where a kernel needs unit rows)
     double *Z;     // U^-T Y[unit rows], YPAD per padded row
     double *At;    // (K^-1 Y[unit rows])^T : per unit YPAD x mp at YPAD*row_off

@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward substitution  U^T [W | Z] = [I | Yu]  (replaces dtrtri/dpotri/dpotrs of gpy_linalg.py:219-253,
+// Forward substitution  U^T [W | Z] = [I | Y[unit rows]]  (replaces dtrtri/dpotri/dpotrs of gpy_linalg.py:219-253,
 // 139-148): one workgroup per 16-column block of the right-hand side, right-looking, the block's
 // running tiles live in MFMA accumulators; only the freshly solved tile goes through LDS.
 // blockIdx.x < max_T : identity column block cb (rows >= cb only, W is lower triangular)
@@ -2542,7 +2542,7 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 //   rank[p]       = points of the same block earlier in the chunk,
 //   cnt[chunk][b] = points of block b in the chunk (written by the block's last point of the chunk; the workgroup
 //                   zeroes its own row first),
-// from which k_blk_scan / k_unit_scan / k_scatter_x derive every table — the points of a block keep ascending index
+// from which k_build (both passes) / k_scatter_x derive every table — the points of a block keep ascending index
 // order, exactly `all_idxs[blocks == i]` (block_clustering.py:21-24).  A point that changes block stamps
 // ctl[CTL_CHANGED] with this evaluation's epoch (no reset needed between evaluations).
 // ------------------------------------------------------------------------------------------------

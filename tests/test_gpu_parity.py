@@ -440,7 +440,7 @@ def _unit_tables(g):
 
 def test_device_built_unit_tables_equal_host_partition_tables():
     """after update_X the unit tables (sizes, offsets, unit row -> point, a point's rows) are built on the
-    device from the device's own partition (k_assign -> k_unit_scan -> k_place).  They must be the tables an uploaded
+    device from the device's own partition (k_assign -> k_build -> k_scatter_x).  They must be the tables an uploaded
     host partition gives (gprf_set_blocks with Blocker.block_clusters' lists): identical row -> point tables, bit-
     identical (ll, gradX, gradC) on every iterate of a walk that re-partitions each time; an iterate that moves nobody
     across a border rebuilds nothing; block_idxs read back equals the host Blocker's."""
@@ -476,7 +476,7 @@ def test_device_built_unit_tables_equal_host_partition_tables():
 
 def test_reblocking_that_outgrows_the_workspace_is_repeated():
     """A re-partition that makes a unit larger than anything the launch was sized for (more tiles per edge, bigger
-    matrix pools) is detected on the device (k_unit_scan), the workspace grows and the evaluation is repeated inside
+    matrix pools) is detected on the device (k_build), the workspace grows and the evaluation is repeated inside
     the same gprf_update_eval call: same numbers as a fresh context on the new partition."""
     from gprf_amd import Blocker, grid_centers, GPCov
     from gprf_amd.gprf import GPRF
