@@ -31,3 +31,6 @@ def test_two_rank_bench_prints_one_contract_line():
     assert d["n_gpus"] == 2 and d["steps"] == 14 and d["warmup"] == 2 and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9
     assert "not a measurement" in d["note"] and d["roofline"]["frac"] > 0
+    # every compute stage's figures ride along, whichever stage is the longest in this run
+    assert set(d["roofline"]["all_stages"]) <= {"potrf", "solve", "at", "grad"} and d["roofline"]["all_stages"]
+    assert all(v["ms"] > 0 and v["frac"] > 0 for v in d["roofline"]["all_stages"].values())
