@@ -118,6 +118,8 @@ struct gprf_ctx {
     DevBuf<double> d_X, d_Y, d_out;
     template <typename T> struct View { T *p = nullptr; };
     View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
+    View<double> d_ewgt;                  // per CSR entry: its unit's Bethe weight (static)
+    DevBuf<int32_t> d_pe, d_ebase;        // k_assemble's per-point / per-entry shortcuts (k_scatter_x)
     DevBuf<int32_t> d_big_list, d_small_list;
     DevBuf<SlotRec> d_srec, d_big_rec, d_small_rec;
     int grid_big = 0, grid_small = 0;     // launch sizes of the Cholesky's two lists (list lengths at the last sync + slack)
@@ -210,6 +212,7 @@ BuildTab make_build(gprf_ctx *c) {
     b.unit_bi = c->d_unit_bi.p; b.unit_bj = c->d_unit_bj.p; b.bu_ptr = c->d_bu_ptr.p; b.bu_ent = c->d_bu_ent.p;
     b.ids = c->d_ids.p; b.big_list = c->d_big_list.p; b.small_list = c->d_small_list.p;
     b.srec = c->d_srec.p; b.big_rec = c->d_big_rec.p; b.small_rec = c->d_small_rec.p;
+    b.pe = c->d_pe.p; b.ebase = c->d_ebase.p;
     b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE && potrf_dual_enabled()) ? potrf_small_maxT() : 0;
     b.grid_big = c->grid_big; b.grid_small = c->grid_small;
     b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
@@ -385,6 +388,8 @@ int rebuild_static(gprf_ctx *c) {
             if (c->l_bj[l] >= 0) bu_ent[cur[c->l_bj[l]]++] = 2 * l + 1;
         }
     }
+    std::vector<double> ewgt(bu_ent.size());
+    for (size_t e = 0; e < bu_ent.size(); ++e) ewgt[e] = weight[(size_t)(bu_ent[e] >> 1)];
     // launch order: largest units first, so that the long factorisations start first
     std::vector<int32_t> ids(nl);
     std::iota(ids.begin(), ids.end(), 0);
@@ -398,6 +403,8 @@ int rebuild_static(gprf_ctx *c) {
     size_t nl1 = (size_t)std::max(nl, 1);
     c->n_chunks = (c->n + CHUNK - 1) / CHUNK;
     HIP_TRY(c, c->d_m.reserve(nl1));
+    HIP_TRY(c, c->d_pe.reserve(2 * (size_t)c->n + 2, 1.0));
+    HIP_TRY(c, c->d_ebase.reserve(bu_ent.size() + 1, 1.0));
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_offj.reserve(nl1));
     HIP_TRY(c, c->d_matoff.reserve(nl1));
@@ -437,6 +444,7 @@ int rebuild_static(gprf_ctx *c) {
             {jitter.data(), (size_t)nl * sizeof(double), (void **)&c->d_jitter.p},
             {bu_ptr.data(), bu_ptr.size() * sizeof(int32_t), (void **)&c->d_bu_ptr.p},
             {bu_ent.data(), bu_ent.size() * sizeof(int32_t), (void **)&c->d_bu_ent.p},
+            {ewgt.data(), ewgt.size() * sizeof(double), (void **)&c->d_ewgt.p},
         };
         size_t total = 256;
         for (auto &sg : segs) total += (sg.bytes + 255) & ~(size_t)255;
@@ -598,6 +606,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     // host_io: d_X / d_out are the pinned host buffers themselves (read / written by the kernels over the fabric) and
     // the result words are mirrored into pinned memory by the assembly kernel: no copy command in the evaluation
     AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c),
+                   c->d_pe.p, c->d_ebase.p, c->d_ewgt.p,
                    c->d_res.p, host_io ? c->h_res.d : nullptr, (int)c->res_words};
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
     launch_scatter_x(make_build(c), d_X, c->dx, c->dist_id, from_chunks, force, c->epoch, s);
@@ -825,7 +834,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
-    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
+    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_pe.release(); c->d_ebase.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
     c->d_cs.release(); c->d_c2.release(); c->d_side.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();

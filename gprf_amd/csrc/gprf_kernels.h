@@ -73,6 +73,7 @@ struct BuildTab {
     const int32_t *ids;      // [n_local] launch order (largest first at the last host build)
     int32_t *big_list, *small_list;   // [n_local] each: the units of more than / at most small_maxT tiles, in ids order
     SlotRec *srec, *big_rec, *small_rec;   // [n_local] each: the launch-slot records (UnitTab)
+    int32_t *pe, *ebase;     // AssembleTab's per-point / per-entry shortcuts, rebuilt with the partition
     int small_maxT;          // 0 = no split
     int grid_big, grid_small;         // launch sizes the lists must fit
     int32_t *m;              // the UnitTab columns this build writes
@@ -135,6 +136,11 @@ struct AssembleTab {
     const int32_t *bu_ent;
     const int32_t *off_j;
     const int32_t *ctl;
+    // per point (first CSR entry of its block, number of entries) and per CSR entry (first unit row of the block inside
+    // that unit; the unit's Bethe weight): the point's rows in two dependent loads instead of four
+    const int32_t *pe;         // [2 n], written by k_scatter_x with the partition
+    const int32_t *ebase;      // [entries], written by k_scatter_x with the partition
+    const double *ewgt;        // [entries], static
     // the context's result words [ctl | info | bsize] are mirrored by the assembly kernel into (host-visible) memory,
     // so that a host-in / host-out evaluation needs no copy command at all; mirror_dst = nullptr: no mirror
     const int32_t *mirror_src;

@@ -2472,11 +2472,10 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
     int t = threadIdx.x, i = t >> 3, e = t & 7;
     int p = (blockIdx.x - 1) * 32 + i;
     bool live = want_gx && p < n && !at.ctl[CTL_OVERFLOW];
-    int b = live ? at.assign[p] : -1;
     int e0 = 0, cnt = 0, pos = 0;
-    if (b >= 0) {
-        e0 = at.bu_ptr[b];
-        cnt = at.bu_ptr[b + 1] - e0;
+    if (live) {      // (first CSR entry of the point's block, number of entries): k_scatter_x left them with the partition
+        e0 = at.pe[2 * p];
+        cnt = at.pe[2 * p + 1];
         pos = at.posb[p];
     }
     if (t == 0) s_maxcnt = 0;
@@ -2488,10 +2487,8 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
     for (int k0 = 0; k0 < maxcnt; k0 += 8) {
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
         if (k0 + e < cnt) {
-            int ent = at.bu_ent[e0 + k0 + e];
-            int u = ent >> 1;
-            int row = ut.row_off[u] + ((ent & 1) ? at.off_j[u] : 0) + pos;
-            double w = ut.weight[u];
+            int row = at.ebase[e0 + k0 + e] + pos;      // = row_off[u] + (second block ? off_j[u] : 0) + pos
+            double w = at.ewgt[e0 + k0 + e];            // = weight[u]
             const double *gr = pl.gXu + (size_t)row * XPAD;
             g0 = w * gr[0]; g1 = w * gr[1]; g2 = w * gr[2];
         }
@@ -2858,7 +2855,10 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= bt.n) return;
     int b = bt.assign[p];
-    if (b < 0) return;
+    if (b < 0) {
+        if (rebuild) { bt.pe[2 * p] = 0; bt.pe[2 * p + 1] = 0; }
+        return;
+    }
     int pos;
     if (rebuild && from_chunks) {
         pos = bt.cnt[(size_t)(p / CHUNK) * bt.n_blocks + b] + bt.rank[p];
@@ -2880,11 +2880,16 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
         r3 = 0.0;
     }
     typedef double d2v __attribute__((ext_vector_type(2)));
-    for (int e = bt.bu_ptr[b]; e < bt.bu_ptr[b + 1]; ++e) {
+    const int e_first = bt.bu_ptr[b], e_end = bt.bu_ptr[b + 1];
+    if (rebuild) { bt.pe[2 * p] = e_first; bt.pe[2 * p + 1] = e_end - e_first; }      // k_assemble's shortcuts
+    for (int e = e_first; e < e_end; ++e) {
         int ent = bt.bu_ent[e];
         int u = ent >> 1;
         int row = bt.row_off[u] + ((ent & 1) ? bt.off_j[u] : 0) + pos;
-        if (rebuild) bt.upt[row] = p;
+        if (rebuild) {
+            bt.upt[row] = p;
+            if (pos == 0) bt.ebase[e] = row;      // the block's first row inside this unit (one writer per entry)
+        }
         d2v *dst = reinterpret_cast<d2v *>(bt.Xu + (size_t)row * (geo ? GEO_STRIDE : XPAD));      // 32- / 64-byte rows
         dst[0] = d2v{r0, r1};
         dst[1] = d2v{r2, r3};
