@@ -147,10 +147,12 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
     (fp64 LAPACK) rows.  Both are rounding noise of the same order whose per-unit maxima scatter by a factor of two either
     way.  Measured on MI355X (12 units, m 149..250): |gpu - true| max 3.0e-8, mean 2.3e-8; |oracle - true| max 2.1e-8, mean
     1.6e-8; ratio mean 1.50, 0.77 .. 2.38 — unit by unit the device's rows are about 1.5x as far from the truth as
-    LAPACK's (not the explicit 16 x 16 diagonal-tile inverses of the forward substitution: a numpy emulation of that
-    algorithm is within 4 % of LAPACK's error, tests/diag/cpu_tile_inverse_emulation.py; what is left is the factorisation
-    itself — reciprocal multiplies in the pivot rows, MFMA accumulation order), while on the ASSEMBLED gradient it is as close
-    or closer (test above).  Asserted with headroom for the scatter: pooled maximum and mean ratio at
+    LAPACK's.  Where it enters (tests/diag/gpu_stage_error.py, tests/diag/cpu_tile_inverse_emulation.py): the device's U and
+    W = U^-T are 1.1-1.2x LAPACK's distance from the 80-bit factors; numpy fp64 fed with the DEVICE's W and A reproduces the
+    device's rows (the MFMA product, the kernel re-evaluation and the reductions add nothing), fed with LAPACK's it reproduces
+    the oracle's; the explicit 16 x 16 tile inverses of the substitution are not it (an emulation with them is within 4 % of
+    LAPACK) — it is the factorisation: reciprocal multiplies in the pivot rows, MFMA accumulation order.  On the ASSEMBLED
+    gradient the device is as close or closer (test above).  Asserted with headroom for the scatter: pooled maximum and mean ratio at
     most 2, no single unit more than 3.5x further from the truth than the oracle is."""
     from ld_truth import unit_llgrad_ld
     g = sdata.build_gprf(local_dist=0.1)
