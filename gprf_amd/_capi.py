@@ -52,6 +52,15 @@ SIGNATURES = {
     "gprf_table_builds": (ctypes.c_int, [_vp, _i32p]),
     "gprf_set_timing": (ctypes.c_int, [_vp, _i32]),
     "gprf_get_timing": (ctypes.c_int, [_vp, _i32, _dp]),
+    "gprf_set_x_prior": (ctypes.c_int, [_vp, _dp, ctypes.c_double]),
+    "gprf_set_hyper_param": (ctypes.c_int, [_vp, _i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_double]),
+    "gprf_objective": (ctypes.c_int, [_vp, _dp, _i32, _dp, _i32, _dp, _dp, _dp, _i32p, _i32p]),
+    "gprf_objective_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32]),
+    "gprf_x_prior": (ctypes.c_int, [ctypes.c_int64, _dp, _dp, ctypes.c_double, _dp, _dp]),
+    "gprf_hyper_unpack": (ctypes.c_int, [_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i32, _dp, _dp]),
+    "gprf_hyper_grad": (ctypes.c_int, [_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i32, _dp, _dp, _dp, _dp]),
+    "gprf_build_flags": (ctypes.c_char_p, []),
     "gprf_debug_run": (ctypes.c_int, [_vp, _dp, _i32]),
     "gprf_debug_fetch": (ctypes.c_int, [_vp, _i32, _i32, _dp, ctypes.c_int64]),
     "gprf_debug_unit_shape": (ctypes.c_int, [_vp, _i32, _i32p, _i32p, _i32p]),
@@ -117,6 +126,11 @@ def _preload_torch_hip_runtime():
             pass
 
 
+def build_flags():
+    """diagnostic defines the loaded library was compiled with ("" = the product build)"""
+    return load().gprf_build_flags().decode().split()
+
+
 def partition_units(m, dy, world):
     """owner rank of every unit (gprf_partition_units; host only, no GPU needed)."""
     m = np.ascontiguousarray(m, dtype=np.int32)
@@ -140,6 +154,46 @@ def nearest_center(X, centers):
     if rc != GPRF_OK:
         raise GprfHipError("gprf_nearest_center failed (%d)" % rc)
     return out
+
+
+HYPER_NONE, HYPER_TIED, HYPER_FULL = 0, 1, 2
+
+
+def x_prior(x, x_obs, obs_std, want_grad=True):
+    """Gaussian location prior N(x_obs, obs_std^2) (gprf_x_prior; host only): -> (log density, gradient or None)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    x_obs = np.ascontiguousarray(x_obs, dtype=np.float64).ravel()
+    if x.shape != x_obs.shape:
+        raise ValueError("x and x_obs differ in size")
+    ll = ctypes.c_double(0.0)
+    g = np.empty_like(x) if want_grad else None
+    rc = load().gprf_x_prior(x.size, dptr(x), dptr(x_obs), float(obs_std), ctypes.byref(ll), dptr(g) if want_grad else None)
+    if rc != GPRF_OK:
+        raise GprfHipError("gprf_x_prior failed (%d)" % rc)
+    return ll.value, g
+
+
+def hyper_unpack(mode, cov_scale, fixed_nv, fixed_sv, ntheta, zh):
+    """theta = [noise_var, signal_var, lengthscales...] from the optimiser's hyper variables (gprf_hyper_unpack)."""
+    zh = np.ascontiguousarray(zh, dtype=np.float64).ravel()
+    theta = np.empty(ntheta)
+    rc = load().gprf_hyper_unpack(mode, float(cov_scale), float(fixed_nv), float(fixed_sv), ntheta, dptr(zh), dptr(theta))
+    if rc != GPRF_OK:
+        raise GprfHipError("gprf_hyper_unpack failed (%d)" % rc)
+    return theta
+
+
+def hyper_grad(mode, cov_scale, prior_mean, prior_std, zh, gradC):
+    """-> (hyper prior log density, d(ll + prior)/d zh) from gradC = d ll / d theta (gprf_hyper_grad)."""
+    zh = np.ascontiguousarray(zh, dtype=np.float64).ravel()
+    gradC = np.ascontiguousarray(gradC, dtype=np.float64).ravel()
+    pll = ctypes.c_double(0.0)
+    g = np.empty_like(zh)
+    rc = load().gprf_hyper_grad(mode, float(cov_scale), float(prior_mean), float(prior_std), gradC.size, dptr(zh), dptr(gradC),
+                                ctypes.byref(pll), dptr(g))
+    if rc != GPRF_OK:
+        raise GprfHipError("gprf_hyper_grad failed (%d)" % rc)
+    return pll.value, g
 
 
 class Context(object):
@@ -276,6 +330,37 @@ class Context(object):
                                        ctypes.byref(reb))
         self._check(rc, "gprf_update_eval")
         return rc, ll.value, gx, gc, bad.value, bool(reb.value)
+
+    def set_x_prior(self, X_obs, obs_std):
+        if X_obs is None:
+            self._check(self.lib.gprf_set_x_prior(self.h, None, 0.0), "gprf_set_x_prior")
+            return
+        X_obs = np.ascontiguousarray(X_obs, dtype=np.float64)
+        assert X_obs.size == self.n * self.dx
+        self._check(self.lib.gprf_set_x_prior(self.h, dptr(X_obs), float(obs_std)), "gprf_set_x_prior")
+
+    def set_hyper_param(self, mode, cov_scale=1.0, prior_mean=0.0, prior_std=1.0, fixed_nv=0.0, fixed_sv=1.0):
+        self._check(self.lib.gprf_set_hyper_param(self.h, mode, float(cov_scale), float(prior_mean), float(prior_std),
+                                                  float(fixed_nv), float(fixed_sv)), "gprf_set_hyper_param")
+
+    def objective(self, z, X_fixed=None, reblock=False):
+        """One optimiser callback in the library (gprf_objective): -> (rc, f, grad, parts, first_bad_unit, reblocked)"""
+        z = np.ascontiguousarray(z, dtype=np.float64).ravel()
+        Xf = None if X_fixed is None else np.ascontiguousarray(X_fixed, dtype=np.float64)
+        f = ctypes.c_double(0.0)
+        g = np.empty_like(z)
+        parts = np.zeros(3)
+        bad, reb = _i32(-1), _i32(0)
+        rc = self.lib.gprf_objective(self.h, dptr(z), z.size, dptr(Xf) if Xf is not None else None, 1 if reblock else 0,
+                                     ctypes.byref(f), dptr(g), dptr(parts), ctypes.byref(bad), ctypes.byref(reb))
+        self._check(rc, "gprf_objective")
+        return rc, f.value, g, parts, bad.value, bool(reb.value)
+
+    def objective_device(self, d_X_ptr, want_gx, want_gc, d_out_ptr, stream_ptr=None, reblock=False):
+        rc = self.lib.gprf_objective_device(self.h, _vp(d_X_ptr), 1 if want_gx else 0, 1 if want_gc else 0, _vp(d_out_ptr),
+                                            _vp(stream_ptr) if stream_ptr else None, 1 if reblock else 0)
+        self._check(rc, "gprf_objective_device")
+        return rc
 
     def get_block_assignment(self):
         out = np.empty(self.n, dtype=np.int32)

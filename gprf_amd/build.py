@@ -23,22 +23,43 @@ def have_compiler():
 
 
 def build(force=False, verbose=False):
+    """Compile to a temporary file next to LIB and rename it into place, under an exclusive lock: with one process per
+    GPU every rank may find the library stale at import — one of them builds, the others wait and find it fresh; nobody
+    ever maps a half-written file."""
     if not force and not _stale():
         return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():      # somebody else built it while this process waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = "%s.tmp.%d" % (LIB, os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
            "-Wl,--no-undefined",      # a symbol one source file declares and the other forgot to define fails HERE
            # k_potrf_reg keeps tiles in explicitly numbered AGPRs behind inline asm: the compiler must never park a
            # spilled VGPR in an AGPR of its own choosing (tests/test_isa_invariants.py checks the ISA)
            "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-o", tmp] + [os.path.join(CSRC, f) for f in SOURCES]
     # diagnostic builds: GPRF_BUILD_DEFS="-DGPRF_PROFILE" compiles the in-kernel cycle stamps in
     cmd[1:1] = os.environ.get("GPRF_BUILD_DEFS", "").split()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

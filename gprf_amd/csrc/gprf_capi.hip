@@ -146,6 +146,14 @@ struct gprf_ctx {
     bool poll_pending = false;            // the pending evaluation ends with k_done: finish_eval may poll
     bool spin = true;                     // GPRF_SYNC=block: hipStreamSynchronize instead of polling
 
+    // the optimiser-facing form (gprf_objective): location prior N(X_obs, obs_std^2) and the log-space hyper-parameters
+    bool xprior = false;
+    double obs_std = 0.0;
+    DevBuf<double> d_Xobs, d_xpart;
+    int hyper_mode = 0;                   // GPRF_HYPER_NONE / TIED / FULL
+    double cov_scale = 1.0, hp_mean = 0.0, hp_std = 1.0, fixed_nv = 0.0, fixed_sv = 1.0;
+    bool objective_call = false;          // the evaluation being enqueued leaves in the optimiser's form
+
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
     static constexpr int RING = 32;
@@ -632,16 +640,36 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         launch_gx_finalize(ut, pl, kp, want_gc, s);
     }
     mark();
-    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, s);
+    // gprf_objective: the result leaves in the optimiser's form; the location prior is added by ONE context of a
+    // sharded job (rank 0), so that the all-reduce of the partial vectors counts it once
+    ObjTab ob{0, nullptr, nullptr, 0.0, 0.0, nullptr};
+    const bool objective = c->objective_call && stop_after >= 5;
+    if (objective) {
+        ob.on = 1;
+        ob.X = d_X;
+        ob.Xobs = (c->xprior && c->rank == 0) ? c->d_Xobs.p : nullptr;
+        ob.sigma = c->obs_std;
+        ob.var = c->obs_std * c->obs_std;
+        ob.part = c->d_xpart.p;
+    }
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, ob, s);
     mark();
-    HIP_TRY(c, hipGetLastError());
     // control words, unit status, block sizes -> pinned host: one download (or the assembly kernel's mirror)
     c->poll_pending = false;
+    const bool poll = host_io && stop_after >= 5 && c->spin && c->h_done.p;
+    if (poll) c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
+    if (objective) {
+        const double nel = (double)c->n * c->dx;
+        const double xp_const = -0.5 * nel * std::log(2.0 * M_PI * (c->obs_std * c->obs_std));
+        size_t nout = 1 + (size_t)c->n * c->dx + c->ncov + 2;
+        launch_finish(d_out, ob, (c->n + 31) / 32, xp_const, host_io ? d_out + nout : nullptr, poll ? c->h_done.d : nullptr,
+                      c->done_seq, s);
+    }
+    HIP_TRY(c, hipGetLastError());
     if (!host_io || stop_after < 5) {
         HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    } else if (c->spin && c->h_done.p) {
-        c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
-        launch_done(c->h_done.d, c->done_seq, s);
+    } else if (poll) {
+        if (!objective) launch_done(c->h_done.d, c->done_seq, s);
         c->poll_pending = true;
     }
     if (!c->ev_last) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
@@ -695,9 +723,32 @@ int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
 
 // after the stream has been synchronised: GPRF_OK / GPRF_NOT_PD / GPRF_RETRY (the partition outgrew the workspace:
 // it has been grown, enqueue the evaluation again without re-partitioning)
+// Wait for stream s without ever blocking for good: an evaluation whose two Cholesky queues wait for each other through
+// stream memory operations cannot finish under a tool that serialises the dispatches of all queues (launch_potrf picks
+// events when it recognises such an environment; this is the net under the ones it does not).  GPRF_EVAL_TIMEOUT_S
+// (default 120) bounds it.
+int bounded_stream_wait(gprf_ctx *c, hipStream_t s) {
+    static const double limit = [] { const char *e = getenv("GPRF_EVAL_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    auto t0 = std::chrono::steady_clock::now();
+    for (long it = 0;; ++it) {
+        hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return GPRF_OK;
+        if (q != hipErrorNotReady) return fail(c, GPRF_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > limit) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "the evaluation did not finish within %.0f s (GPRF_EVAL_TIMEOUT_S): a tool that serialises "
+                     "dispatches across queues? set GPRF_POTRF_DUAL=2 (one queue) or GPRF_SIDE_EVENTS=1", limit);
+            return fail(c, GPRF_ERR_HIP, buf);
+        }
+        if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 1000 : 50));
+        else __builtin_ia32_pause();
+    }
+}
+
 int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *reblocked) {
     if (c->poll_pending) {
-        // spin on the sequence number k_done stores into pinned memory (bounded: fall back to the runtime's wait)
+        // spin on the sequence number k_done stores into pinned memory (bounded: fall back to querying the stream)
         volatile int32_t *flag = c->h_done.p;
         auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
@@ -705,14 +756,16 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
             __builtin_ia32_pause();
             if ((++spins & 0xfff) == 0 &&
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
-                HIP_TRY(c, hipStreamSynchronize(s));
+                int rc = bounded_stream_wait(c, s);
+                if (rc != GPRF_OK) { c->poll_pending = false; c->eval_pending = false; return rc; }
                 break;
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         c->poll_pending = false;
     } else {
-        HIP_TRY(c, hipStreamSynchronize(s));
+        int rc = bounded_stream_wait(c, s);
+        if (rc != GPRF_OK) { c->eval_pending = false; return rc; }
     }
     c->eval_pending = false;
     if (first_bad_unit) *first_bad_unit = -1;
@@ -737,7 +790,7 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
 
 // host X in -> host result out, optionally re-partitioning first; repeats when the workspace had to grow
 int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll_out, double *gradX_out,
-                double *gradC_out, int32_t *first_bad_unit, bool reblock, int32_t *reblocked) {
+                double *gradC_out, int32_t *first_bad_unit, bool reblock, int32_t *reblocked, bool objective = false) {
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
     size_t nout = 1 + nx + c->ncov + 2;
@@ -747,7 +800,9 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
     (void)nout;
     int any_reblocked = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
+        c->objective_call = objective;
         int rc = enqueue_eval(c, c->h_X.d, want_gx, want_gc, c->h_out.d, s, 6, reblock, true);
+        c->objective_call = false;
         if (rc != GPRF_OK) return rc;
         int32_t rb = 0;
         rc = finish_eval(c, s, first_bad_unit, &rb);
@@ -817,7 +872,8 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
     if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
         c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
-        c->h_out.reserve(nout) != hipSuccess || c->h_done.reserve(16) != hipSuccess) {
+        c->h_out.reserve(nout + 4) != hipSuccess || c->h_done.reserve(16) != hipSuccess ||
+        c->d_xpart.reserve((size_t)(n + 31) / 32 + 1, 1.0) != hipSuccess) {
         gprf_destroy(c);
         return GPRF_ERR_HIP;
     }
@@ -836,7 +892,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
     c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_pe.release(); c->d_ebase.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
-    c->d_cs.release(); c->d_c2.release(); c->d_side.release();
+    c->d_cs.release(); c->d_c2.release(); c->d_side.release(); c->d_Xobs.release(); c->d_xpart.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
     c->d_tleaf.release();
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();
@@ -1249,6 +1305,149 @@ int gprf_update_eval(gprf_ctx *c, const double *X, int32_t want_gradX, int32_t w
     return run_checked(c, X, want_gradX, want_gradC, ll_out, gradX_out, gradC_out, first_bad_unit, true, reblocked);
 }
 
+// ---- the optimiser-facing objective (gprfopt.py:320-417): pure host pieces first ----
+int gprf_x_prior(int64_t n_elems, const double *x, const double *x_obs, double obs_std, double *ll_out, double *grad_out) {
+    if (n_elems < 0 || (n_elems > 0 && (!x || !x_obs)) || !ll_out || !(obs_std > 0.0)) return GPRF_ERR_ARG;
+    const double var = obs_std * obs_std;
+    // blocked summation (32 elements x dx lanes per partial on the device; here blocks of 64): error growth like the
+    // pairwise sum numpy uses, fixed order
+    double total = 0.0;
+    for (int64_t i0 = 0; i0 < n_elems; i0 += 64) {
+        double part = 0.0;
+        const int64_t i1 = std::min<int64_t>(n_elems, i0 + 64);
+        for (int64_t i = i0; i < i1; ++i) {
+            const double d = x[i] - x_obs[i];
+            const double r = d / obs_std;
+            part += r * r;
+            if (grad_out) grad_out[i] = -d / var;
+        }
+        total += part;
+    }
+    *ll_out = -0.5 * total - 0.5 * (double)n_elems * std::log(2.0 * M_PI * var);
+    return GPRF_OK;
+}
+
+static int hyper_count(int32_t mode, int32_t ncov) { return mode == GPRF_HYPER_TIED ? 1 : (mode == GPRF_HYPER_FULL ? ncov : 0); }
+
+int gprf_hyper_unpack(int32_t mode, double cov_scale, double fixed_nv, double fixed_sv, int32_t ncov, const double *zh,
+                      double *theta_out) {
+    if (ncov < 3 || !theta_out || (mode != GPRF_HYPER_TIED && mode != GPRF_HYPER_FULL) || !zh || !(cov_scale > 0.0))
+        return GPRF_ERR_ARG;
+    if (mode == GPRF_HYPER_TIED) {
+        const double ls = std::exp(zh[0] / cov_scale);
+        theta_out[0] = fixed_nv;
+        theta_out[1] = fixed_sv;
+        for (int t = 2; t < ncov; ++t) theta_out[t] = ls;
+    } else {
+        for (int t = 0; t < ncov; ++t) theta_out[t] = std::exp(zh[t] / cov_scale);
+    }
+    return GPRF_OK;
+}
+
+int gprf_hyper_grad(int32_t mode, double cov_scale, double prior_mean, double prior_std, int32_t ncov, const double *zh,
+                    const double *gradC, double *prior_ll_out, double *grad_zh_out) {
+    if (ncov < 1 || (mode == GPRF_HYPER_TIED && ncov < 3) || (mode != GPRF_HYPER_TIED && mode != GPRF_HYPER_FULL) || !zh ||
+        !gradC || !prior_ll_out || !grad_zh_out || !(cov_scale > 0.0) || !(prior_std > 0.0))
+        return GPRF_ERR_ARG;
+    const int nh = hyper_count(mode, ncov);
+    const double pvar = prior_std * prior_std;
+    double ss = 0.0;
+    for (int t = 0; t < nh; ++t) {
+        const double cl = zh[t] / cov_scale;                 // the log parameter
+        const double r = (cl - prior_mean) / prior_std;
+        ss += r * r;
+        // chain rule through theta = exp(cl): d ll / d cl = (d ll / d theta) theta; a tied lengthscale collects every
+        // lengthscale's derivative
+        double dth = 0.0;
+        if (mode == GPRF_HYPER_TIED)
+            for (int q = 2; q < ncov; ++q) dth += gradC[q];
+        else
+            dth = gradC[t];
+        grad_zh_out[t] = (dth * std::exp(cl) + -(cl - prior_mean) / pvar) / cov_scale;
+    }
+    *prior_ll_out = -0.5 * ss - 0.5 * (double)nh * std::log(2.0 * M_PI * pvar);
+    return GPRF_OK;
+}
+
+int gprf_set_x_prior(gprf_ctx *c, const double *X_obs, double obs_std) {
+    if (!c) return GPRF_ERR_ARG;
+    if (!X_obs) { c->xprior = false; return GPRF_OK; }
+    if (!(obs_std > 0.0) || !std::isfinite(obs_std)) return fail(c, GPRF_ERR_ARG, "obs_std must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t nx = (size_t)c->n * c->dx;
+    HIP_TRY(c, c->d_Xobs.reserve(nx + 1, 1.0));
+    if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (nx) HIP_TRY(c, hipMemcpy(c->d_Xobs.p, X_obs, nx * sizeof(double), hipMemcpyHostToDevice));
+    c->obs_std = obs_std;
+    c->xprior = true;
+    return GPRF_OK;
+}
+
+int gprf_set_hyper_param(gprf_ctx *c, int32_t mode, double cov_scale, double prior_mean, double prior_std,
+                         double fixed_noise_var, double fixed_signal_var) {
+    if (!c) return GPRF_ERR_ARG;
+    if (mode != GPRF_HYPER_NONE && mode != GPRF_HYPER_TIED && mode != GPRF_HYPER_FULL)
+        return fail(c, GPRF_ERR_ARG, "unknown hyper-parameter mode");
+    if (mode != GPRF_HYPER_NONE && (!(cov_scale > 0.0) || !(prior_std > 0.0)))
+        return fail(c, GPRF_ERR_ARG, "cov_scale and prior_std must be positive");
+    c->hyper_mode = mode; c->cov_scale = cov_scale; c->hp_mean = prior_mean; c->hp_std = prior_std;
+    c->fixed_nv = fixed_noise_var; c->fixed_sv = fixed_signal_var;
+    return GPRF_OK;
+}
+
+int gprf_objective(gprf_ctx *c, const double *z, int32_t nz, const double *X_fixed, int32_t reblock, double *f_out,
+                   double *grad_out, double *parts_out, int32_t *first_bad_unit, int32_t *reblocked) {
+    if (!c || !f_out || !grad_out || (nz > 0 && !z)) return GPRF_ERR_ARG;
+    const int nx = c->xprior ? c->n * c->dx : 0;
+    const int nh = hyper_count(c->hyper_mode, c->ncov);
+    if (nz != nx + nh) return fail(c, GPRF_ERR_ARG, "z must hold [locations (when a location prior is set) | hyper-parameters]");
+    if (nx == 0 && !X_fixed) return fail(c, GPRF_ERR_ARG, "no location prior set: pass the (fixed) locations");
+    if (nh > 0) {
+        std::vector<double> theta((size_t)c->ncov);
+        int rc = gprf_hyper_unpack(c->hyper_mode, c->cov_scale, c->fixed_nv, c->fixed_sv, c->ncov, z + nx, theta.data());
+        if (rc != GPRF_OK) return fail(c, rc, "gprf_hyper_unpack");
+        rc = gprf_set_theta(c, theta.data(), c->ncov);
+        if (rc != GPRF_OK) return rc;
+    }
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (reblock && c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double *X = nx ? z : X_fixed;
+    double f = 0.0;
+    std::vector<double> gC((size_t)c->ncov, 0.0);
+    // gradX goes straight into the caller's vector (already negated, prior included: k_assemble)
+    rc = run_checked(c, X, nx ? 1 : 0, nh ? 1 : 0, &f, grad_out, gC.data(), first_bad_unit, reblock != 0, reblocked, true);
+    if (rc != GPRF_OK) return rc;
+    const size_t nout = 1 + (size_t)c->n * c->dx + c->ncov + 2;
+    double hp_ll = 0.0;
+    if (nh > 0) {
+        rc = gprf_hyper_grad(c->hyper_mode, c->cov_scale, c->hp_mean, c->hp_std, c->ncov, z + nx, gC.data(), &hp_ll,
+                             grad_out + nx);
+        if (rc != GPRF_OK) return fail(c, rc, "gprf_hyper_grad");
+        for (int t = 0; t < nh; ++t) grad_out[nx + t] = -grad_out[nx + t];
+        f -= hp_ll;
+    }
+    *f_out = f;
+    if (parts_out) { parts_out[0] = c->h_out.p[nout]; parts_out[1] = c->h_out.p[nout + 1]; parts_out[2] = hp_ll; }
+    return GPRF_OK;
+}
+
+int gprf_objective_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
+                          void *stream, int32_t reblock) {
+    int rc = check_ready(c);
+    if (rc != GPRF_OK) return rc;
+    if (!d_X || !d_out) return GPRF_ERR_ARG;
+    if (reblock && c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->objective_call = true;
+    rc = enqueue_eval(c, d_X, want_gradX, want_gradC, d_out, s, 6, reblock != 0);
+    c->objective_call = false;
+    return rc;
+}
+
 int gprf_num_units(const gprf_ctx *c, int32_t *n_total, int32_t *n_local) {
     if (!c) return GPRF_ERR_ARG;
     if (n_total) *n_total = c->n_blocks + c->n_pairs;
@@ -1268,6 +1467,57 @@ int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
     if (flops) *flops = c->work_flops;
     if (fill_bytes) *fill_bytes = c->work_fill_bytes;
     return GPRF_OK;
+}
+
+// every diagnostic define the sources know (ablations skip work inside the timed kernels; stamps / traces cost registers)
+const char *gprf_build_flags(void) {
+    return ""
+#ifdef GPRF_PROFILE
+           " GPRF_PROFILE"
+#endif
+#ifdef GPRF_WGTRACE
+           " GPRF_WGTRACE"
+#endif
+#ifdef GPRF_ABL
+           " GPRF_ABL"
+#endif
+#ifdef GPRF_ABL_NOFACTOR
+           " GPRF_ABL_NOFACTOR"
+#endif
+#ifdef GPRF_ABL_NODUMP
+           " GPRF_ABL_NODUMP"
+#endif
+#ifdef GPRF_ABL_NOSUBST
+           " GPRF_ABL_NOSUBST"
+#endif
+#ifdef GPRF_ABL_NOCOPY
+           " GPRF_ABL_NOCOPY"
+#endif
+#ifdef GPRF_ABL_NOTRAIL
+           " GPRF_ABL_NOTRAIL"
+#endif
+#ifdef GPRF_ABL_NOEPI
+           " GPRF_ABL_NOEPI"
+#endif
+#ifdef GPRF_ABL_MG_NOMMA
+           " GPRF_ABL_MG_NOMMA"
+#endif
+#ifdef GPRF_ABL_MG_NOEPI
+           " GPRF_ABL_MG_NOEPI"
+#endif
+#ifdef GPRF_MGRAD_FINE
+           " GPRF_MGRAD_FINE"
+#endif
+#ifdef GPRF_MGRAD_LOOP
+           " GPRF_MGRAD_LOOP"
+#endif
+#ifdef GPRF_SOLVE_STAMP_PART
+           " GPRF_SOLVE_STAMP_PART"
+#endif
+#ifdef GPRF_SOLVE_GLDS
+           " GPRF_SOLVE_GLDS"
+#endif
+        ;
 }
 
 int gprf_last_reblocked(const gprf_ctx *c, int32_t *reblocked) {

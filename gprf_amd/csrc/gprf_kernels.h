@@ -148,6 +148,16 @@ struct AssembleTab {
     int mirror_n;
 };
 
+// The optimiser-facing form of the result (gprf_objective; gprfopt.py:377-417): the assembly adds the location prior's
+// terms and flips the signs, so that what comes down in the evaluation's one download is what scipy's minimiser consumes.
+struct ObjTab {
+    int on;                  // 0: the plain (ll, gradX, gradC)
+    const double *X;         // the points of this evaluation (n x dx)
+    const double *Xobs;      // prior means; nullptr: this context adds no location prior (none set, or not the owner rank)
+    double sigma, var;       // obs_std and its square
+    double *part;            // [gradX workgroups of k_assemble] partial sums of ((x - x_obs) / sigma)^2
+};
+
 // re-blocking: nearest centre / split-tree descent of every point, with the per-chunk ranks and counts the table
 // build starts from (bt.assign / rank / cnt; ctl[CTL_CHANGED] = epoch when somebody moved)
 void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt,
@@ -181,7 +191,9 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
                  bool have_K, hipStream_t s);
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s);
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
-                     int want_gx, int want_gc, double *out, int usum_ok, hipStream_t s);
+                     int want_gx, int want_gc, double *out, int usum_ok, const ObjTab &ob, hipStream_t s);
+void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, double *extras, int32_t *flag, int32_t seq,
+                   hipStream_t s);
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s);
 // threshold neighbour discovery: keep[c] = max |k| / sv over candidate block pair c > thr (early out unless want_max)
 void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const int64_t *blk_ptr, const int32_t *blk_pts,

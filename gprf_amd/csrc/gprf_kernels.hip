@@ -2402,7 +2402,7 @@ __global__ __launch_bounds__(256) void k_gx_finalize(UnitTab ut, Pools pl, KPara
 // out = [ll | gradX (n x dx) | gradC (2 + ndfn) | overflow flag | units not PD]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, AssembleTab at, KParams kp, int n,
-                                                  int want_gx, int want_gc, double *out, int usum_ok) {
+                                                  int want_gx, int want_gc, double *out, int usum_ok, ObjTab ob) {
     int dx = kp.dx;
     if (blockIdx.x == 0) {
         __shared__ double red[256][6];
@@ -2500,7 +2500,60 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
         }
         __syncthreads();
     }
+    // gprf_objective: the optimiser's form of the result — the location prior's gradient -(x - x_obs) / sigma^2 added
+    // here (gprfopt.py:172-182, 396-399), signs flipped (gprfopt.py:417); the prior's log-density leaves as one partial
+    // sum of ((x - x_obs) / sigma)^2 per workgroup, folded in a fixed order by k_finish
+    double r2 = 0.0;
+    if (ob.on && p < n && e < dx) {
+        if (ob.Xobs) {
+            double d = ob.X[(size_t)p * dx + e] - ob.Xobs[(size_t)p * dx + e];
+            double r = d / ob.sigma;
+            r2 = r * r;
+            v += -d / ob.var;
+        }
+        v = -v;
+    }
     if (p < n && e < dx) out[1 + (size_t)p * dx + e] = v;
+    if (ob.on && ob.Xobs) {      // (uniform)
+        __shared__ double r2w[4];
+        for (int off = 32; off >= 1; off >>= 1) r2 += shfl_xor_d(r2, off);
+        if ((t & 63) == 0) r2w[t >> 6] = r2;
+        __syncthreads();
+        if (t == 0) ob.part[blockIdx.x - 1] = (r2w[0] + r2w[1]) + (r2w[2] + r2w[3]);
+    }
+}
+
+// k_finish (gprf_objective only; takes k_done's place at the end of a host-in / host-out evaluation): out[0] = -(ll +
+// location prior), the prior's partial sums folded in a fixed order; xp_const = -1/2 N log(2 pi sigma^2) (gprfopt.py:178).
+// extras (may be nullptr) <- [ll of the GPRF terms alone, location prior].
+__global__ __launch_bounds__(256) void k_finish(double *out, ObjTab ob, int nparts, double xp_const, double *extras,
+                                                int32_t *flag, int32_t seq) {
+    __shared__ double red[256];
+    int t = threadIdx.x;
+    double s = 0.0;
+    if (ob.Xobs)
+        for (int i = t; i < nparts; i += 256) s += ob.part[i];
+    red[t] = s;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (t < h) red[t] += red[t + h];
+        __syncthreads();
+    }
+    if (t == 0) {
+        double ll = out[0];
+        double xp = ob.Xobs ? -0.5 * red[0] + xp_const : 0.0;
+        out[0] = -(ll + xp);
+        if (extras) { extras[0] = ll; extras[1] = xp; }
+        if (flag) {
+            __threadfence_system();
+            __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+        }
+    }
+}
+
+void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, double *extras, int32_t *flag, int32_t seq,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, out, ob, nparts, xp_const, extras, flag, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2976,6 +3029,18 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 return (e && e[0] == '2') || (c && c[0] && c[0] != '0' && c[0] != 'F' && c[0] != 'f');
             }();
             if (serial) s2 = s;      // the two instantiations one after the other on the main queue
+            // Any OTHER environment that may serialise dispatches across queues — a profiler or debug agent loaded into the
+            // runtime, serialised / blocking launches — gets the fork and the join as EVENTS: dependencies the runtime itself
+            // resolves (slower: stage 131 vs 110 us), where a stream wait on a word that a kernel of the other queue
+            // writes would never return.  (finish_eval bounds its wait all the same.)
+            static const bool tool_env = [] {
+                for (const char *v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "AMD_SERIALIZE_KERNEL",
+                                      "HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION", "GPRF_SIDE_EVENTS"}) {
+                    const char *e = getenv(v);
+                    if (e && e[0] && !(e[0] == '0' && e[1] == 0)) return true;
+                }
+                return false;
+            }();
             const bool dual = potrf_dual_enabled();
             if (dual && s2 && ut.max_T > POTRF_SMALL_MAXT) {
                 // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
@@ -2995,7 +3060,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // 4 (default): no fork command — the large-unit kernel's first workgroup writes the word the side queue
                 // waits for — + join by memory operation: stage 110 (the event fork costs 12 us, all of it in front of the
                 // small-unit kernel, which finishes last)
-                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : 4; }();
+                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : (tool_env ? 0 : 4); }();
                 const bool fork_values = side.words && (side_mode == 1 || side_mode == 2);
                 const bool join_values = side.words && (side_mode == 1 || side_mode == 3 || side_mode == 4);
                 // mode 4: no fork command at all — the large-unit kernel's first workgroup writes the word the side queue
@@ -3232,9 +3297,9 @@ __global__ void k_done(int32_t *flag, int32_t seq) {
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_done, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
-                     int want_gx, int want_gc, double *out, int usum_ok, hipStream_t s) {
+                     int want_gx, int want_gc, double *out, int usum_ok, const ObjTab &ob, hipStream_t s) {
     int blocks = 1 + (n + 31) / 32;
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out, usum_ok);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, ut, p, at, kp, n, want_gx, want_gc, out, usum_ok, ob);
 }
 
 }  // namespace gprf

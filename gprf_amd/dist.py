@@ -13,6 +13,7 @@ import numpy as np
 from . import _capi
 
 N_STATUS = 2      # status words behind [ll | gradX | gradC] (include/gprf_hip.h, gprf_eval_device)
+FATAL = 2.0 ** 40  # first status word of a rank whose library call failed (a count of ranks otherwise: far below)
 
 
 def out_len(n, dx, ncov):
@@ -84,6 +85,17 @@ def agree_first_bad(bad, group=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     v = int(t.item())
     return -1 if v == big else v
+
+
+def agree_any(flag, group=None, device=None):
+    """True on every rank iff ``flag`` is true on some rank (one MAX all-reduce of one word; error paths only)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())
 
 
 def jitter_schedule(evaluate, first_bad, n_units, diag_mean, start=None):
@@ -169,20 +181,38 @@ class DeviceEvaluator(object):
         return unpack_out(self.d_out.cpu().numpy(), self.n, self.dx, self.ncov, grad_X, grad_cov)
 
     # ------------------------------------------------------------------ the optimiser-visible call
-    def _round(self, grad_X, grad_cov, reblock):
-        """one evaluation + all-reduce + download, fully finished: -> (host vector, local status, local bad unit)"""
+    def _round(self, grad_X, grad_cov, reblock, objective=False):
+        """one evaluation + all-reduce + download, fully finished: -> (host vector, local status, local bad unit, error).
+
+        Nothing raises between the collectives: a rank whose library call fails still takes part in the all-reduce, with
+        a zero vector whose first status word is FATAL, and hands its error back — ``evaluate`` raises it on every rank
+        together (a rank that left the loop alone would leave the others waiting in a collective)."""
         torch, st = self.torch, self.stream
+        no = out_len(self.n, self.dx, self.ncov)
+        err = None
         with torch.cuda.stream(st):
-            self.g._ctx.eval_device(self.h_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream,
-                                    reblock=reblock)
+            enqueue = self.g._ctx.objective_device if objective else self.g._ctx.eval_device
+            try:
+                enqueue(self.h_X.data_ptr(), grad_X, grad_cov, self.d_out.data_ptr(), st.cuda_stream, reblock=reblock)
+            except _capi.GprfHipError as e:
+                err = e
+                self.d_out.zero_()
+                self.d_out[no - 2] = FATAL
             allreduce_sum_(self.d_out, self.group)
             self.h_out.copy_(self.d_out, non_blocking=True)
         st.synchronize()
-        rc, bad = self.g._ctx.eval_status()
-        return self.h_out.numpy(), rc, bad
+        rc, bad = -1, -1
+        if err is None:
+            try:
+                rc, bad = self.g._ctx.eval_status()
+            except _capi.GprfHipError as e:      # e.g. the new partition has a unit beyond GPRF_MAX_UNIT points
+                err = e
+        return self.h_out.numpy(), rc, bad, err
 
-    def evaluate(self, X, grad_X=False, grad_cov=False, reblock=False):
-        """-> (ll, gradX, gradC, reblocked) with jitchol's retry applied identically on every rank."""
+    def evaluate(self, X, grad_X=False, grad_cov=False, reblock=False, objective=False):
+        """-> (ll, gradX, gradC, reblocked) with jitchol's retry applied identically on every rank.
+        ``objective``: the optimiser's form (gprf_objective_device): -(ll + location prior), -(gradX + its gradient),
+        gradC unchanged."""
         torch, st = self.torch, self.stream
         # X goes into pinned host memory and the kernels read it from there (the partition kernel, which runs first when
         # re-blocking, leaves a copy in HBM for the others; without re-blocking only k_scatter_x reads it): no copy command
@@ -193,11 +223,21 @@ class DeviceEvaluator(object):
         def run(reblock_now):
             # repeat while ANY rank's new partition outgrew its workspace (that rank has grown it by now)
             for _ in range(4):
-                buf, rc, bad = self._round(grad_X, grad_cov, reblock_now)
+                buf, rc, bad, err = self._round(grad_X, grad_cov, reblock_now, objective)
+                if buf[no - 2] >= FATAL:                 # some rank's enqueue failed: everybody leaves here
+                    raise err or _capi.GprfHipError("another rank's evaluation failed")
+                if buf[no - 2] == 0.0:
+                    if err is not None:
+                        raise err                        # (a failed synchronisation: nothing left to agree on)
+                    if reblock_now and g._ctx.last_reblocked():
+                        reblocked[0] = True
+                    return buf, bad
+                # some rank's re-partition outgrew its workspace.  Growing it may have failed there (a unit past
+                # GPRF_MAX_UNIT points, out of memory): agree before anybody enters the next round's collective
+                if agree_any(err is not None, self.group, self.dev):
+                    raise err or _capi.GprfHipError("another rank could not install the new partition")
                 if reblock_now and g._ctx.last_reblocked():
                     reblocked[0] = True
-                if buf[no - 2] == 0.0:
-                    return buf, bad
                 reblock_now = False
             raise _capi.GprfHipError("the unit tables did not fit the workspace after growing it three times")
 

@@ -109,6 +109,8 @@ class GPRF(object):
             self._reblock_pending = False
             if changed:
                 self._block_of, self._block_idxs = block_of, None
+                self._blocks_pushed = "device"       # the library holds exactly this partition: nothing to upload (an upload
+                                                     # would also re-deal the shard ownership on this rank alone)
         if self._block_idxs is None:
             if self._block_of is None:
                 self._block_of = self._ctx.get_block_assignment()
@@ -272,6 +274,75 @@ class GPRF(object):
         gradX = gX if grad_X else np.zeros((0, 0))
         gradCov = gC.reshape((1, -1)) if grad_cov else np.zeros((0, 0))
         return ll, gradX, gradCov
+
+    # ------------------------------------------------------------------ the optimiser's callback, in the library
+    def objective_setup(self, X_obs, obs_std, hyper_mode, cov_scale, hyper_prior, fixed_nv, fixed_sv):
+        """Install what ``gprf_objective`` needs (include/gprf_hip.h): the location prior N(X_obs, obs_std^2) — None when
+        the locations are not optimised — and the log-space parametrisation of the hyper-parameters."""
+        self._ctx.set_x_prior(X_obs, obs_std)
+        self._ctx.set_hyper_param(hyper_mode, cov_scale, hyper_prior[0], hyper_prior[1], fixed_nv, fixed_sv)
+        self._objective_par = (hyper_mode, cov_scale, hyper_prior)
+
+    def objective_call(self, z, layout):
+        """One callback of the optimiser (gprfopt.py:377-417) as ONE library call: unpack z, re-block (update_X), evaluate,
+        add the priors, chain rule, signs -> (f, grad, (GPRF terms, location prior, hyper prior)).  The object's ``X`` /
+        ``cov`` / ``noise_var`` follow z like ``update_X`` / ``update_covs`` would leave them."""
+        if layout.nx:
+            self.update_X(layout.locations(z))
+        if layout.nh:
+            theta = layout.theta_row(z)
+            self.cov = GPCov(wfn_params=[theta[0, 1]], dfn_params=theta[0, 2:], dfn_str=self.cov.dfn_str, wfn_str=self.cov.wfn_str)
+            self.noise_var = theta[0, 0]
+        self._push_blocks()
+        if self._jitter is not None:
+            self._jitter = None
+            self._ctx.set_unit_jitter(None)
+        self._push_neighbors(self.neighbors)
+        X_fixed = None if layout.nx else np.ascontiguousarray(self.X, dtype=np.float64)
+        if self._shard[1] > 1 and self._reduce:
+            return self._objective_sharded(z, layout, X_fixed)
+        reblock, self._reblock_pending = self._reblock_pending, False
+        rc, f, grad, parts, bad, reblocked = self._ctx.objective(z, X_fixed, reblock=reblock)
+        if reblocked:
+            self._block_of, self._block_idxs = None, None
+            self._blocks_pushed = "device"
+        if rc == _capi.GPRF_NOT_PD:
+            from .dist import jitter_schedule
+            n_units = self.n_blocks + len(self._nbrs_pushed)
+
+            def ev(jitter):
+                self._ctx.set_unit_jitter(jitter)
+                self._jitter = jitter
+                rc2, f2, g2, p2, b2, _ = self._ctx.objective(z, X_fixed, reblock=False)
+                return (f2, g2, p2), (b2 if rc2 == _capi.GPRF_NOT_PD else -1)
+
+            (f, grad, parts), _ = jitter_schedule(ev, bad, n_units, self.cov.wfn_params[0] + self.noise_var, self._jitter)
+        return f, grad, tuple(parts)
+
+    def _objective_sharded(self, z, layout, X_fixed):
+        """the same callback over a sharded job: rank 0's context adds the location prior, ONE all-reduce, then the
+        hyper-parameter chain rule on the host (ntheta numbers)"""
+        from . import dist as gdist
+        if self._dist_eval is None:
+            self._dist_eval = gdist.DeviceEvaluator(self, self._group)
+        X = layout.locations(z) if layout.nx else X_fixed
+        if layout.nh:
+            self._push_theta()
+        reblock, self._reblock_pending = self._reblock_pending, False
+        f, gX, gC, reblocked = self._dist_eval.evaluate(X, layout.nx > 0, layout.nh > 0, reblock=reblock, objective=True)
+        if reblocked:
+            self._block_of, self._block_idxs = None, None
+            self._blocks_pushed = "device"
+        grad = np.empty(layout.nx + layout.nh)
+        hp = 0.0
+        if layout.nx:
+            grad[:layout.nx] = gX.ravel()
+        if layout.nh:
+            mode, cov_scale, prior = self._objective_par
+            hp, hg = _capi.hyper_grad(mode, cov_scale, prior[0], prior[1], z[layout.nx:], gC)
+            grad[layout.nx:] = -hg
+            f -= hp
+        return f, grad, (None, None, hp)
 
     def _llgrad_sharded(self, X, grad_X, grad_cov):
         """This rank's units on this GPU, ONE all-reduce (sum) over the ranks, the same result on every rank."""

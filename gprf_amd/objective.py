@@ -1,121 +1,176 @@
-"""The L-BFGS-B objective callback around the GPRF path — counterpart of
-``gprfopt.do_optimization`` (gprfopt.py:320-432): ``lgpllgrad`` with the X prior (gprfopt.py:172-182),
-the log-space covariance parametrisation scaled by ``cov_scale = 5`` and its near-uniform prior
-(gprfopt.py:324-331, 365-368, 383, 403-407), ``full_cov`` / ``collapse_cov_grad`` (gprfopt.py:333-355)
-and the ``log.txt`` line format (gprfopt.py:411-413).  Per-evaluation ``np.save`` checkpoints
-(gprfopt.py:388,394) are optional."""
+"""Adapter between ``scipy.optimize`` and the library's objective entry point.
+
+The reference wraps ``GPRF.llgrad`` in a closure before handing it to L-BFGS-B (gprfopt.py:320-432): it unpacks the
+optimiser's flat vector, adds a Gaussian prior around the observed locations and a wide prior on the log
+hyper-parameters, applies the chain rule and flips the signs.  Here that arithmetic lives in ``libgprf_hip.so``
+(``gprf_objective``, include/gprf_hip.h): the location prior is added by the assembly kernel and the result comes down
+already in the optimiser's layout, in the evaluation's one download.  What is left in Python is bookkeeping:
+
+* ``VectorLayout``  — which slice of the flat vector is what, and the constants of the parametrisation;
+* ``RunLog``        — the ``log.txt`` lines / optional ``.npy`` checkpoints of a run and the in-memory trace;
+* ``Objective``     — the callable scipy sees; it routes to the library (a ``gprf_amd.GPRF``) or, for any other object
+                      with the ``update_X / update_covs / llgrad`` surface, to the library's host-side prior functions.
+"""
 import os
 import time
 
 import numpy as np
 import scipy.optimize
 
+from . import _capi
+
 
 class OutOfTimeError(Exception):
     pass
 
 
+# the reference's constants: the optimiser sees log-parameters stretched by 5 (gprfopt.py:364) under a N(-1, 10^2)
+# prior (gprfopt.py:325)
+COV_SCALE = 5.0
+HYPER_PRIOR = (-1.0, 10.0)
+
+
 def cov_prior(c):
-    """gprfopt.py:324-331"""
-    mean, std = -1, 10
-    r = (c - mean) / std
-    ll = -.5 * np.sum(r ** 2) - .5 * len(c) * np.log(2 * np.pi * std ** 2)
-    return ll, -(c - mean) / (std ** 2)
+    """log density and gradient of the hyper-parameter prior at the log parameters ``c`` (gprfopt.py:324-331)"""
+    c = np.atleast_1d(np.asarray(c, dtype=np.float64)).ravel()
+    return _capi.hyper_grad(_capi.HYPER_FULL, 1.0, HYPER_PRIOR[0], HYPER_PRIOR[1], c, np.zeros_like(c))
+
+
+class VectorLayout(object):
+    """z = [locations, row-major | cov_scale * log(free hyper-parameters)].
+
+    ``C0`` of shape (1, 1) frees one lengthscale shared by every input dimension, with the noise variance pinned to the
+    data's and the signal variance to 1 (gprfopt.py:333-355); (1, 2 + n_lengthscales) frees everything."""
+
+    def __init__(self, X0, C0, noise_var, ntheta):
+        self.x_shape = None if X0 is None else tuple(np.shape(X0))
+        self.nx = 0 if X0 is None else int(np.prod(self.x_shape))
+        self.ntheta = ntheta
+        self.noise_var = noise_var
+        if C0 is None:
+            self.mode, self.nh, self.c_shape = _capi.HYPER_NONE, 0, None
+        else:
+            C0 = np.asarray(C0, dtype=np.float64)
+            self.c_shape = C0.shape
+            if C0.shape[1] == 1:
+                self.mode, self.nh = _capi.HYPER_TIED, 1
+            elif C0.shape[1] == ntheta:
+                self.mode, self.nh = _capi.HYPER_FULL, ntheta
+            else:
+                raise Exception("unrecognized cov param shape")
+        self.start = np.concatenate([np.zeros(0) if X0 is None else np.asarray(X0, dtype=np.float64).ravel(),
+                                     np.zeros(0) if C0 is None else COV_SCALE * np.log(C0.ravel())])
+
+    def locations(self, z):
+        return z[:self.nx].reshape(self.x_shape)
+
+    def theta_row(self, z):
+        """the (1, ntheta) row ``GPRF.update_covs`` takes"""
+        return _capi.hyper_unpack(self.mode, COV_SCALE, self.noise_var, 1.0, self.ntheta, z[self.nx:]).reshape(1, -1)
+
+
+class RunLog(object):
+    """``log.txt`` ("step seconds objective", gprfopt.py:411-413), optional per-step checkpoints (gprfopt.py:388,394)."""
+
+    def __init__(self, log_dir, checkpoint):
+        self.dir, self.checkpoint = log_dir, bool(checkpoint and log_dir)
+        self.fh = open(os.path.join(log_dir, "log.txt"), "w") if log_dir else None
+        self.t0 = time.time()
+        self.rows = []
+
+    def elapsed(self):
+        return time.time() - self.t0
+
+    def record(self, ll):
+        step, secs = len(self.rows), self.elapsed()
+        self.rows.append((step, secs, ll))
+        if self.fh:
+            self.fh.write("%d %.2f %.2f\n" % (step, secs, ll))
+            self.fh.flush()
+
+    def save(self, what, array):
+        if self.checkpoint:
+            np.save(os.path.join(self.dir, "step_%05d_%s.npy" % (len(self.rows), what)), array)
+
+    def close(self):
+        if self.fh:
+            self.fh.write("optimization finished after %.fs\n" % self.elapsed())
+            self.fh.close()
+            self.fh = None
 
 
 class Objective(object):
-    """``obj(x) -> (-ll, -grad)`` for ``scipy.optimize.minimize(..., jac=True)``."""
+    """``obj(z) -> (-log posterior, -gradient)`` for ``scipy.optimize.minimize(..., jac=True)``."""
 
-    cov_scale = 5.  # gprfopt.py:364
+    cov_scale = COV_SCALE
 
     def __init__(self, gprf, X0, C0, sdata, maxsec=None, log_dir=None, checkpoint=False, parallel=False):
-        self.gprf, self.X0, self.C0, self.sdata = gprf, X0, C0, sdata
-        self.gradX, self.gradC = (X0 is not None), (C0 is not None)
-        x0 = X0.flatten() if self.gradX else np.array(())
-        c0 = np.log(C0.flatten()) * self.cov_scale if self.gradC else np.array(())
-        self.nx = len(x0)
-        self.full0 = np.concatenate([x0, c0])
-        self.maxsec, self.parallel = maxsec, parallel
-        self.log_dir, self.checkpoint = log_dir, checkpoint
-        self.f_log = open(os.path.join(log_dir, "log.txt"), "w") if log_dir else None
-        self.step = 0
-        self.t0 = time.time()
-        self.trace = []  # (step, secs, ll)
+        self.gprf, self.sdata, self.maxsec = gprf, sdata, maxsec
+        ntheta = 2 + np.shape(sdata.X_obs)[1]
+        self.layout = VectorLayout(X0, C0, sdata.noise_var, ntheta)
+        self.log = RunLog(log_dir, checkpoint)
+        self.parts = None                   # (GPRF terms, location prior, hyper prior) of the last call
+        self._native = hasattr(gprf, "objective_call")
+        if self._native:
+            gprf.objective_setup(sdata.X_obs if self.layout.nx else None, sdata.obs_std, self.layout.mode, COV_SCALE,
+                                 HYPER_PRIOR, sdata.noise_var, 1.0)
 
-    def full_cov(self, C):
-        """gprfopt.py:333-345"""
-        if C.shape[1] == 1:
-            FC = np.empty((self.C0.shape[0], 2 + self.sdata.X_obs.shape[1]))
-            FC[:, 0] = self.sdata.noise_var
-            FC[:, 1] = 1.0
-            FC[:, 2:3] = C
-            FC[:, 3:4] = C
-            return FC
-        if C.shape[1] == 4:
-            return C
-        raise Exception("unrecognized cov param shape")
+    # names the reference's callers (and this repository's tests) read
+    full0 = property(lambda self: self.layout.start)
+    nx = property(lambda self: self.layout.nx)
+    trace = property(lambda self: self.log.rows)
+    step = property(lambda self: len(self.log.rows))
+    t0 = property(lambda self: self.log.t0)
 
-    def collapse_cov_grad(self, grad_FC):
-        """gprfopt.py:347-355"""
-        if self.C0.shape[1] == 1:
-            return grad_FC[:, 2:3] + grad_FC[:, 3:4]
-        if self.C0.shape[1] == 4:
-            return grad_FC
-        raise Exception("unrecognized cov param shape")
-
-    def __call__(self, x):
-        if self.maxsec is not None and time.time() - self.t0 > self.maxsec:
+    def __call__(self, z):
+        if self.maxsec is not None and self.log.elapsed() > self.maxsec:
             raise OutOfTimeError
-        xx = x[:self.nx]
-        xc = x[self.nx:] / self.cov_scale
-        if self.gradX:
-            XX = xx.reshape(self.X0.shape)
-            self.gprf.update_X(XX)
-            if self.checkpoint and self.log_dir:
-                np.save(os.path.join(self.log_dir, "step_%05d_X.npy" % self.step), XX)
-        if self.gradC:
-            C = np.exp(xc.reshape(self.C0.shape))
-            FC = self.full_cov(C)
-            self.gprf.update_covs(FC)
-            if self.checkpoint and self.log_dir:
-                np.save(os.path.join(self.log_dir, "step_%05d_cov.npy" % self.step), FC)
-        ll, gX, gC = self.gprf.llgrad(local=True, grad_X=self.gradX, grad_cov=self.gradC, parallel=self.parallel)
-        if self.gradX:
-            prior_ll, prior_grad = self.sdata.x_prior(xx)
-            ll += prior_ll
-            gX = gX.flatten() + prior_grad
-        if self.gradC:
-            prior_ll, prior_grad = cov_prior(xc)
-            ll += prior_ll
-            gC = (np.array(self.collapse_cov_grad(gC)) * C).flatten() + prior_grad
-            gC /= self.cov_scale
-        grad = np.concatenate([gX.flatten(), gC.flatten()])
-        secs = time.time() - self.t0
-        self.trace.append((self.step, secs, ll))
-        if self.f_log:
-            self.f_log.write("%d %.2f %.2f\n" % (self.step, secs, ll))
-            self.f_log.flush()
-        self.step += 1
-        return -ll, -grad
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        lay = self.layout
+        if lay.nx:
+            self.log.save("X", lay.locations(z))
+        if lay.nh:
+            self.log.save("cov", lay.theta_row(z))
+        if self._native:
+            f, grad, self.parts = self.gprf.objective_call(z, lay)
+        else:
+            f, grad, self.parts = self._through_llgrad(z)
+        self.log.record(-f)
+        return f, grad
+
+    def _through_llgrad(self, z):
+        """any model with the reference's surface: the model's llgrad, then the library's host-side prior terms"""
+        lay, g = self.layout, self.gprf
+        if lay.nx:
+            g.update_X(lay.locations(z))
+        if lay.nh:
+            g.update_covs(lay.theta_row(z))
+        ll, gX, gC = g.llgrad(local=True, grad_X=lay.nx > 0, grad_cov=lay.nh > 0)
+        grad = np.empty(lay.nx + lay.nh)
+        xp = hp = 0.0
+        if lay.nx:
+            xp, xg = _capi.x_prior(z[:lay.nx], self.sdata.X_obs, self.sdata.obs_std)
+            grad[:lay.nx] = -(np.asarray(gX).ravel() + xg)
+        if lay.nh:
+            hp, hg = _capi.hyper_grad(lay.mode, COV_SCALE, HYPER_PRIOR[0], HYPER_PRIOR[1], z[lay.nx:], gC)
+            grad[lay.nx:] = -hg
+        return -(ll + xp + hp), grad, (ll, xp, hp)
 
     def close(self):
-        if self.f_log:
-            self.f_log.write("optimization finished after %.fs\n" % (time.time() - self.t0))
-            self.f_log.close()
-            self.f_log = None
+        self.log.close()
 
 
 def do_optimization(gprf, X0, C0, sdata, method="l-bfgs-b", maxsec=3600, log_dir=None, maxiter=200, **kw):
-    """gprfopt.py:320-432.  Returns (x_final or None if timed out, Objective)."""
+    """The optimiser run of the reference's drivers (gprfopt.py:419-432: ftol 1e-6, no bounds; a ``finished`` marker in
+    the run directory).  Returns (final vector, or None when the time budget ran out; the Objective with its trace)."""
     obj = Objective(gprf, X0, C0, sdata, maxsec=maxsec, log_dir=log_dir, **kw)
-    rx = None
+    z_final = None
     try:
-        r = scipy.optimize.minimize(obj, obj.full0, jac=True, method=method, bounds=None,
-                                    options={"ftol": 1e-6, "maxiter": maxiter})
-        rx = r.x
+        z_final = scipy.optimize.minimize(obj, obj.full0, jac=True, method=method, bounds=None,
+                                          options={"ftol": 1e-6, "maxiter": maxiter}).x
     except OutOfTimeError:
         pass
     obj.close()
     if log_dir:
         open(os.path.join(log_dir, "finished"), "w").close()
-    return rx, obj
+    return z_final, obj

@@ -150,27 +150,27 @@ class SampledData(object):
         self.reblock = b.block_clusters      # bound method: GPRF.update_X recognises it and re-blocks in C
         self.neighbors = b.neighbors(diag_connections=True)
 
+    def model_hypers(self, theta_row=None):
+        """(GPCov, noise variance) of a model over this data: the sampling hyper-parameters, or the row
+        [noise_var, signal_var, lengthscales...] a driver passes around (gprf.py:160-164)."""
+        if theta_row is None:
+            return self.cov, self.noise_var
+        theta = np.asarray(theta_row, dtype=np.float64)
+        if theta.ndim != 2 or theta.shape[0] != 1:
+            raise Exception("invalid cov params %s" % (theta_row,))
+        return GPCov(wfn_params=[theta[0, 1]], dfn_params=theta[0, 2:], dfn_str="euclidean", wfn_str="se"), theta[0, 0]
+
     def build_gprf(self, X=None, cov=None, local_dist=1e-4, **kw):
-        """gprfopt.py:55-74: neighbours are used iff local_dist < 1.0."""
+        """The model the reference's driver optimises (gprfopt.py:55-74): grid blocks re-evaluated at every ``update_X``,
+        the blocker's neighbour pairs when ``local_dist`` < 1 and none (independent local GPs) otherwise."""
         from .gprf import GPRF
-        if X is None:
-            X = self.X_obs
-        if cov is None:
-            cov, noise_var = self.cov, self.noise_var
-        elif cov.shape[0] == 1:
-            noise_var = cov[0, 0]
-            cov = GPCov(wfn_params=[cov[0, 1]], dfn_params=cov[0, 2:], dfn_str="euclidean", wfn_str="se")
-        else:
-            raise Exception("invalid cov params %s" % (cov,))
-        return GPRF(X, Y=self.SY, block_fn=self.reblock, block_idxs=self.block_idxs, cov=cov, noise_var=noise_var,
-                    kernelized=False, neighbor_threshold=local_dist,
-                    neighbors=self.neighbors if local_dist < 1.0 else [], **kw)
+        gpcov, noise_var = self.model_hypers(cov)
+        pairs = self.neighbors if local_dist < 1.0 else []
+        return GPRF(self.X_obs if X is None else X, Y=self.SY, block_fn=self.reblock, block_idxs=self.block_idxs,
+                    cov=gpcov, noise_var=noise_var, kernelized=False, neighbor_threshold=local_dist, neighbors=pairs, **kw)
 
     def x_prior(self, xx):
-        """gprfopt.py:172-182"""
-        flatobs = self.X_obs.flatten()
-        n = len(xx)
-        r = (xx - flatobs) / self.obs_std
-        ll = -.5 * np.sum(r ** 2) - .5 * n * np.log(2 * np.pi * self.obs_std ** 2)
-        lderiv = -(xx - flatobs) / (self.obs_std ** 2)
-        return ll, lderiv
+        """log density and gradient of the location prior N(X_obs, obs_std^2 I) at the flat vector ``xx``
+        (gprfopt.py:172-182), evaluated by the library's host function (``gprf_x_prior``)."""
+        from . import _capi
+        return _capi.x_prior(xx, self.X_obs, self.obs_std)

@@ -174,6 +174,46 @@ int gprf_eval_status(gprf_ctx *ctx, int32_t *first_bad_unit);
 /* Whether the evaluation gprf_eval_status last finished changed the partition (host-side flag, no device access). */
 int gprf_last_reblocked(const gprf_ctx *ctx, int32_t *reblocked);
 
+/* ---- The optimiser-facing objective: what the reference's drivers wrap around llgrad before handing it to scipy's
+ * L-BFGS-B (gprfopt.py:320-417, do_optimization.lgpllgrad): the vector z = [X.flatten() | hyper-parameters in log space
+ * times cov_scale], the Gaussian location prior around the observed positions (x_prior, gprfopt.py:172-182), the
+ * near-uniform prior on the log hyper-parameters (cov_prior, gprfopt.py:324-331), the chain rule through exp
+ * (gprfopt.py:403-407) and the sign flip (gprfopt.py:417).  The location prior's terms are added by the assembly kernel
+ * and the result comes down already in the optimiser's layout, in the evaluation's one download. ---- */
+#define GPRF_HYPER_NONE 0 /* hyper-parameters fixed (task x) */
+#define GPRF_HYPER_TIED 1 /* one free parameter: the common lengthscale; noise / signal variance fixed
+                             (full_cov / collapse_cov_grad with a 1-column C, gprfopt.py:333-355) */
+#define GPRF_HYPER_FULL 2 /* every entry of theta free (the 4-column C of gprfopt.py:343,352) */
+
+/* N(X_obs, obs_std^2 I) prior on the locations (gprfopt.py:172-182); X_obs: n x dx, copied.  With a prior set, z of
+ * gprf_objective starts with the n*dx locations.  NULL removes it. */
+int gprf_set_x_prior(gprf_ctx *ctx, const double *X_obs, double obs_std);
+/* Hyper-parameter part of z: zh = cov_scale * log(free parameters) (gprfopt.py:364-368,383), each log parameter with
+ * a N(prior_mean, prior_std^2) prior (gprfopt.py:324-331: mean -1, std 10).  TIED: theta = [fixed_noise_var,
+ * fixed_signal_var, l, l, ...] (gprfopt.py:336-341 pins them to the data's noise variance and 1.0). */
+int gprf_set_hyper_param(gprf_ctx *ctx, int32_t mode, double cov_scale, double prior_mean, double prior_std,
+                         double fixed_noise_var, double fixed_signal_var);
+/* One call of the optimiser's callback (gprfopt.py:377-417): z (nz = [n*dx if a location prior is set] + [1 | ntheta | 0
+ * hyper-parameters]) -> *f_out = -(ll + priors), grad_out (nz) = -d(ll + priors)/dz.  X_fixed: the locations when they are
+ * not part of z (no location prior set), else ignored.  reblock != 0: re-partition first, like gprf_update_eval
+ * (gprf.update_X inside the callback, gprfopt.py:385).  parts_out (may be NULL) <- [ll of the GPRF terms, location prior,
+ * hyper-parameter prior].  Return values and first_bad_unit / reblocked as gprf_update_eval. */
+int gprf_objective(gprf_ctx *ctx, const double *z, int32_t nz, const double *X_fixed, int32_t reblock, double *f_out,
+                   double *grad_out, double *parts_out, int32_t *first_bad_unit, int32_t *reblocked);
+/* The device-resident form (sharded runs all-reduce it): as gprf_eval_device / gprf_update_eval_device, but d_out =
+ * [-(ll + location prior) | -(gradX + prior gradient) | gradC (unchanged: the hyper-parameter chain rule is host work on
+ * ntheta numbers, gprf_hyper_grad) | s0 | s1].  In a sharded job only rank 0's context adds the location prior, so a
+ * SUM all-reduce counts it once. */
+int gprf_objective_device(gprf_ctx *ctx, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
+                          void *stream, int32_t reblock);
+/* The host pieces on their own (no context, no GPU): the location prior (ll_out; grad_out may be NULL), theta from the
+ * optimiser's hyper variables, and d(ll + prior)/d zh from gradC = d ll / d theta (not negated; *prior_ll_out = the prior). */
+int gprf_x_prior(int64_t n_elems, const double *x, const double *x_obs, double obs_std, double *ll_out, double *grad_out);
+int gprf_hyper_unpack(int32_t mode, double cov_scale, double fixed_noise_var, double fixed_signal_var, int32_t ntheta,
+                      const double *zh, double *theta_out);
+int gprf_hyper_grad(int32_t mode, double cov_scale, double prior_mean, double prior_std, int32_t ntheta, const double *zh,
+                    const double *gradC, double *prior_ll_out, double *grad_zh_out);
+
 /* Bookkeeping a caller may want. */
 int gprf_num_units(const gprf_ctx *ctx, int32_t *n_units_total, int32_t *n_units_local);
 /* sum over local units of the algorithmic work of SURVEY.md §8d: flops = m^3 + 4 m^2 dy,
@@ -182,6 +222,11 @@ int gprf_work_estimate(gprf_ctx *ctx, double *flops, double *fill_bytes);
 /* How many times the unit tables have been (re)built on the device since the context was created (tests: an
  * evaluation whose re-partition moved nobody must not rebuild). */
 int gprf_table_builds(gprf_ctx *ctx, int32_t *builds);
+
+/* The diagnostic defines this library was compiled with (in-kernel cycle stamps, workgroup traces, ablations that skip
+ * work inside the kernels): "" for the product build — tests assert that, so that no measured number comes from a
+ * diagnostic variant.  Space-separated names otherwise. */
+const char *gprf_build_flags(void);
 
 /* HIP-event timing of the kernels, recorded on the stream the evaluation is enqueued on.
  * Stages: "gather","fill","potrf","solve","at","grad","assemble".  gprf_set_timing(ctx, 1) turns recording

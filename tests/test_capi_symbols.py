@@ -32,6 +32,23 @@ def test_python_binding_covers_header():
     _capi.load()
 
 
+def test_shipped_library_is_the_product_build():
+    """No diagnostic define (in-kernel stamps, workgroup traces, ablations that skip work) in the library that tests and
+    bench.py load: gprf_build_flags() reports what the sources were compiled with."""
+    assert _capi.build_flags() == [], _capi.build_flags()
+    assert not os.environ.get("GPRF_BUILD_DEFS") and not os.environ.get("GPRF_LIB")
+
+
+def test_stub_b_of_integration_md_parses():
+    """the block tests/test_gpu_stub_b.py executes on the GPU box is there and is valid Python"""
+    import ast
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sect = text[text.index("## B. Minimal stub"):]
+    code = re.search(r"```python\n(.*?)```", sect, flags=re.S).group(1)
+    tree = ast.parse(code)
+    assert any(isinstance(n, ast.ClassDef) and n.name == "HipLLGrad" for n in tree.body)
+
+
 def test_header_cites_reference_interfaces():
     text = open(os.path.join(ROOT, "include", "gprf_hip.h")).read()
     for cite in ("gprf.py:206-296", "gprf.py:496-591", "gprf.py:160-167", "gpy_linalg.py:77-97"):

@@ -86,6 +86,27 @@ def _worker(rank, world, port, q):
             dist.all_reduce(t)
             out[key + "_after"] = float(t.item())
             gs.close()
+        # --- a re-partition that grows ONE unit past GPRF_MAX_UNIT points: fatal on the rank that owns it only
+        from gprf_amd import Blocker, grid_centers
+        rng = np.random.RandomState(8)
+        Xa = rng.rand(1200, 2)
+        bl = Blocker(grid_centers(4))
+        gb = GPRF(Xa, rng.randn(1200, 3), bl.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01,
+                  neighbors=bl.neighbors(), shard=(rank, world))
+        gb.llgrad(grad_X=True)
+        Xb = Xa.copy()
+        Xb[:1100] = np.array(grid_centers(4))[rng.randint(0, 2, 1100)] + 0.01 * rng.randn(1100, 2)   # 1100 points in blocks 0, 1
+        gb.update_X(Xb)
+        try:
+            gb.llgrad(grad_X=True)
+            out["too_big"] = "returned"
+        except _capi.GprfHipError as e:
+            out["too_big"] = "raised: %s" % e
+        t = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        out["too_big_after"] = float(t.item())
+        out["too_big_owner"] = int(_capi.partition_units(np.array([300] * 4 + [600] * 6, dtype=np.int32), 3, world)[4])
+        gb.close()
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -139,3 +160,8 @@ def test_two_rank_optimisation_and_jitter_in_lockstep():
     for r in (a, b):
         assert r["hopeless"][0] == "raised" and "not positive definite" in r["hopeless"][1].lower()
         assert r["hopeless_after"] == 2.0
+    # the unit past GPRF_MAX_UNIT: BOTH ranks raise (the owner with the library's message), nobody hangs
+    for r in (a, b):
+        assert r["too_big"].startswith("raised"), r["too_big"]
+        assert r["too_big_after"] == 2.0
+    assert any("GPRF_MAX_UNIT" in r["too_big"] for r in (a, b)) and any("another rank" in r["too_big"] for r in (a, b))

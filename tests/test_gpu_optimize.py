@@ -72,3 +72,44 @@ def test_lbfgs_reproduces_published_trace(published, local_dist, nblocks):
         assert "%.8f" % err == step["mean_loc_err"]
         assert "%.8f" % sd.x_prior(xs[k])[0] == step["x_prior"]
     g.close()
+
+
+@pytest.mark.parametrize("task", ["x", "xcov", "cov4"])
+def test_library_objective_equals_reference_callback(task):
+    """gprf_objective (priors added by the assembly kernel, result in the optimiser's layout) against the oracle's literal
+    callback (gprfopt.py:377-417) and against the same library driven through update_X / update_covs / llgrad."""
+    from gprf_amd.synthetic import SampledData
+    from gprf_amd import grid_centers
+    from gprf_amd.objective import Objective
+    from oracle.harness_ref import ObjectiveRef, SampledDataRef, grid_centers as ogc
+    kw = dict(n=1000, ntrain=500, lscale=0.4, obs_std=0.04, yd=10, seed=0)
+    sd, so = SampledData(**kw), SampledDataRef(**kw)
+    sd.set_centers(grid_centers(4))
+    so.set_centers(ogc(4))
+    C0 = {"x": None, "xcov": np.array([[0.35]]), "cov4": np.array([[0.012, 1.1, 0.35, 0.45]])}[task]
+    X0 = None if task == "cov4" else sd.X_obs
+    g = sd.build_gprf(local_dist=0.5)
+    obj = Objective(g, X0, C0, sd)
+    assert obj._native
+    oref = ObjectiveRef(so.build_gprf(local_dist=0.5), None if task == "cov4" else so.X_obs, C0, so)
+    rng = np.random.RandomState(4)
+    z = obj.full0 + 0.01 * rng.randn(len(obj.full0))
+    for zz in (obj.full0, z):
+        f, gr = obj(zz)
+        fr, grr = oref(zz)
+        assert np.isclose(f, fr, rtol=1e-12)
+        assert np.allclose(gr, grr, rtol=1e-9, atol=1e-9 * np.abs(grr).max())
+        assert np.isclose(sum(obj.parts), -f, rtol=1e-13)
+        # the same through the reference-shaped surface of the same object
+        class _Surface(object):
+            update_X, update_covs, llgrad = g.update_X, g.update_covs, g.llgrad
+        via = Objective(_Surface(), X0, C0, sd)
+        if task == "cov4":
+            g.update_X(sd.X_obs)
+        f2, gr2 = via(zz)
+        assert np.isclose(f, f2, rtol=1e-13) and np.allclose(gr, gr2, rtol=1e-11, atol=1e-11 * np.abs(gr2).max())
+    if task != "cov4":
+        assert np.array_equal(g.X, obj.layout.locations(z))
+    if task != "x":
+        assert np.isclose(g.cov.dfn_params[0], np.exp(z[obj.nx:][-1] / 5.0 if task == "xcov" else z[obj.nx + 2] / 5.0), rtol=1e-14)
+    g.close()

@@ -107,10 +107,39 @@ def test_objective_transforms_match_reference_callback(task):
     x = a.full0 + 0.01 * rng.randn(len(a.full0))
     fa, ga = a(x)
     fb, gb = b(x)
-    assert fa == fb and np.array_equal(ga, gb)
+    # (the library's host functions sum the prior in blocks, numpy pairwise: equal to rounding, not to the bit)
+    assert np.isclose(fa, fb, rtol=1e-14, atol=0) and np.allclose(ga, gb, rtol=1e-14, atol=0)
+    assert np.allclose(a.gprf.X, b.gprf.X) and (task == "x" or np.allclose(a.gprf.FC, b.gprf.FC, rtol=1e-15))
     assert np.array_equal(a.full0, b.full0)
     assert a.trace[0][0] == 0 and a.step == 1
-    assert pobj.cov_prior(np.array([0.3]))[0] == H.cov_prior(np.array([0.3]))[0]
+    assert np.isclose(sum(a.parts), -fa, rtol=1e-14)
+    assert np.isclose(pobj.cov_prior(np.array([0.3]))[0], H.cov_prior(np.array([0.3]))[0], rtol=1e-15)
+    assert np.allclose(pobj.cov_prior(np.array([0.3, -2.0, 7.0]))[1], H.cov_prior(np.array([0.3, -2.0, 7.0]))[1], rtol=1e-15)
+
+
+def test_library_host_prior_functions():
+    """gprf_x_prior / gprf_hyper_unpack / gprf_hyper_grad (pure host code of the C ABI) against the oracle's restatement of
+    gprfopt.py:172-182, 324-355."""
+    from gprf_amd import _capi
+    rng = np.random.RandomState(2)
+    x, xo = rng.rand(10007), rng.rand(10007)
+    class _S(object):
+        X_obs, obs_std = xo, 0.03
+    rll, rg = H.SampledDataRef.x_prior(_S, x)
+    ll, g = _capi.x_prior(x, xo, 0.03)
+    assert np.isclose(ll, rll, rtol=1e-14) and np.array_equal(g, rg)
+    assert _capi.x_prior(x, xo, 0.03, want_grad=False)[1] is None
+    th = _capi.hyper_unpack(_capi.HYPER_TIED, 5.0, 0.01, 1.0, 4, np.array([5 * np.log(0.3)]))
+    assert np.allclose(th, [0.01, 1.0, 0.3, 0.3], rtol=1e-15)
+    th = _capi.hyper_unpack(_capi.HYPER_FULL, 5.0, 0.0, 0.0, 4, 5 * np.log([0.02, 1.5, 0.3, 0.4]))
+    assert np.allclose(th, [0.02, 1.5, 0.3, 0.4], rtol=1e-15)
+    gC = np.array([3.0, -2.0, 0.7, 1.1])
+    z = np.array([5 * np.log(0.3)])
+    pll, gz = _capi.hyper_grad(_capi.HYPER_TIED, 5.0, -1.0, 10.0, z, gC)
+    rpl, rpg = H.cov_prior(z / 5.0)
+    assert np.isclose(pll, rpl, rtol=1e-15) and np.allclose(gz, ((0.7 + 1.1) * 0.3 + rpg) / 5.0, rtol=1e-15)
+    with pytest.raises(_capi.GprfHipError):
+        _capi.hyper_unpack(7, 5.0, 0.01, 1.0, 4, z)
 
 
 def test_log_line_format(tmp_path):
@@ -146,7 +175,12 @@ def test_synthetic_recipe_matches_oracle_recipe():
     b.set_centers(H.grid_centers(4))
     assert a.neighbors == b.neighbors
     assert all(np.array_equal(u, v) for u, v in zip(a.block_idxs, b.block_idxs))
-    assert a.x_prior(a.X_obs.flatten() + 0.01)[0] == b.x_prior(b.X_obs.flatten() + 0.01)[0]
+    assert np.isclose(a.x_prior(a.X_obs.flatten() + 0.01)[0], b.x_prior(b.X_obs.flatten() + 0.01)[0], rtol=1e-14)
+    th = np.array([[0.02, 1.3, 0.4, 0.5]])
+    cov, nv = a.model_hypers(th)
+    assert nv == 0.02 and cov.wfn_params == [1.3] and list(cov.dfn_params) == [0.4, 0.5]
+    with pytest.raises(Exception):
+        a.model_hypers(np.zeros((2, 4)))
 
 
 def _cases_euclid():
