@@ -479,6 +479,105 @@ __device__ __forceinline__ int diag_factor16(double (&s)[16], int lr_in, double 
     return badmask ? __builtin_ctzll(badmask) + 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// diag_factor16_ldl: the same 16x16 factor with the square roots taken OFF the pivot chain.
+// A dependent fp64 VALU operation costs ~16 cycles of latency here (4 to issue) and a tile's 16 pivots are one serial
+// chain: with  p -> rsqrt(p) (seed, two Newton steps, corrections) -> scale -> update  that chain was 22 dependent
+// operations per pivot (380 cycles measured, 6.1 k per tile: the longest item of a Cholesky step).  The root-free
+// ordering keeps the pivot ROW unscaled:
+//     r_k = row k of the trailing tile (p_k = r_kk),   w_k = r_k / p_k,   s[i][j] -= w_ki r_kj    (i, j > k)
+// so the chain per pivot is  p -> 1/p (seed + two Newton steps) -> w -> first update : 8 dependent operations, and the
+// independent updates of pivot k-1 are issued in its shadows — everything is volatile asm in exactly that order (left
+// to itself the scheduler packs independent work in FRONT of a dependent chain, not into it).  The roots are taken
+// once, behind the loop, for all 16 pivots in parallel (lane k owns p_k):  U_kj = r_kj / sqrt(p_k).
+// Rounding: an update term w_ki r_kj carries ONE rounded quotient (the scaled form's u_ki u_kj carries two); a stored
+// factor entry is r_kj times a reciprocal root, as in LAPACK's dpotf2.
+// Leaves the rows w_k of G = D^-1 U in LDS (Gd[k][lane]; meaningful right of the diagonal): the row panel's forward
+// substitution with the UNIT triangular G has one fused multiply-add per step on its chain instead of three operations.
+// On return s[k] = row k of U (the part LEFT of the diagonal is unspecified: nobody reads it), *dk / *rdk = this lane's
+// diagonal entry and its reciprocal; the result is the first bad pivot (1-based) or 0.
+// ------------------------------------------------------------------------------------------------
+// dst = (lane index == K) ? src : dst, compare and selects in ONE ordered block: neither a lane mask kept in SGPRs from
+// far ahead nor a copy of the lane index per use (both are what the compiler makes of sixteen of these in a row)
+template <int K>
+__device__ __forceinline__ void select_lane(double &dst, double src, int lr) {
+    int dlo = __double2loint(dst), dhi = __double2hiint(dst);
+    asm volatile("v_cmp_eq_u32_e32 vcc, %4, %5\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %1, %3, vcc"
+                 : "+v"(dlo), "+v"(dhi)
+                 : "v"(__double2loint(src)), "v"(__double2hiint(src)), "n"(K), "v"(lr)
+                 : "vcc");
+    dst = __hiloint2double(dhi, dlo);
+}
+template <int L>
+__device__ __forceinline__ void fnma_bcast16_ordered(double &acc, double src, double mul) {      // fnma_bcast16, kept in program order
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
+}
+template <int K, int LO, int HI>
+__device__ __forceinline__ void ldl_pending(double (&s)[16], double wprev) {
+    // updates of pivot K-1 still owed to rows LO .. HI-1:  s[i][lane] -= w_{K-1}[i] * r_{K-1}[lane]
+    static_for<LO, (HI < 16 ? HI : 16)>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        fnma_bcast16_ordered<i>(s[i], wprev, s[K - 1]);
+    });
+}
+
+__device__ __forceinline__ int diag_factor16_ldl(double (&s)[16], int lr_in, double *dk, double *rdk, double *Gd) {
+    double w[2] = {0.0, 0.0};
+    // (LDS byte address of this lane's column of G: the rows are stored from inside the ordered sequence)
+    unsigned ga = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)(Gd + lr_in);
+    static_for<0, 16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int NF = k >= 1 ? 15 - k : 0;      // rows k+1 .. 15 still owed pivot k-1's update (row k had it on the chain)
+        constexpr int PER = (NF + 4) / 5;            // ... dealt over the five gaps of this pivot's chain
+        constexpr int B = k + 1;
+        constexpr int KP = k >= 1 ? k : 1;
+        double pk, y, e;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pk) : "v"(s[k]), "n"(k));
+        if constexpr (k >= 1) ldl_pending<KP, B, B + PER>(s, w[(k - 1) & 1]);
+        asm volatile("v_rcp_f64 %0, %1" : "=v"(y) : "v"(pk));
+        if constexpr (k >= 1) ldl_pending<KP, B + PER, B + 2 * PER>(s, w[(k - 1) & 1]);
+        asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(pk), "v"(y));
+        if constexpr (k >= 1) ldl_pending<KP, B + 2 * PER, B + 3 * PER>(s, w[(k - 1) & 1]);
+        asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(y) : "v"(e));
+        if constexpr (k >= 1) ldl_pending<KP, B + 3 * PER, B + 4 * PER>(s, w[(k - 1) & 1]);
+        asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(pk), "v"(y));
+        if constexpr (k >= 1) ldl_pending<KP, B + 4 * PER, 16>(s, w[(k - 1) & 1]);
+        asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(y) : "v"(e));
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(w[k & 1]) : "v"(s[k]), "v"(y));
+        // (two wait states between the VALU write of w and its first DPP read)
+        if constexpr (k < 15)
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                         : "+v"(s[k + 1])
+                         : "v"(w[k & 1]), "v"(s[k]), "n"(k + 1));
+        // off the chain: the row of G (ordered too: a store the compiler is free to delay keeps its value alive, and the
+        // two-per-CU instantiation has 96 registers)
+        unsigned ga_k = ga;      // (a C++ use: inline-asm operands alone do not make a generic lambda capture a variable)
+        asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(ga_k), "v"(w[k & 1]), "n"(k * 128) : "memory");
+    });
+    // this lane's own pivot p_lr = r_lr,lr: row lr has not changed since it was the pivot row
+    double mypiv = s[0];
+    static_for<1, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        select_lane<i>(mypiv, s[i], lr_in);
+    });
+    // the roots, all pivots at once
+    double d, rd;
+    sqrt_and_rsqrt(mypiv, &d, &rd);
+    dpp_src_ready(rd);
+    static_for<0, 16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double bc;      // (volatile: one broadcast value alive at a time — sixteen hoisted ones would not fit the 96-register kernel)
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(bc) : "v"(rd), "n"(k));
+        double u = s[k] * bc;
+        select_lane<k>(u, d, lr_in);
+        s[k] = u;
+    });
+    *dk = d;
+    *rdk = rd;
+    unsigned long long badmask = __ballot(!(mypiv > 0.0)) & 0xffffull;
+    return badmask ? __builtin_ctzll(badmask) + 1 : 0;
+}
+
 // shared tail of the Cholesky kernels: V_jj = U_jj^-1 for every diagonal tile (wanted by the triangular-solve
 // kernels' MFMA form; 4 tiles per wave at a time, lane (lg, lr) = row lr of tile 4*grp + lg, by the column
 // operations that reduce U_jj to I) and log|K| = 2 sum log U_kk (gpy_linalg.py:234) in a fixed order.
@@ -556,7 +655,8 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     double *Ud = P + 16 * ldp;            // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *Tt = rdt + 16;                // [16][17]  look-ahead tile, row-major
-    double *dvals = Tt + 16 * 17;         // [mp]      diagonal of U
+    double *Gd = Tt + 16 * 17;            // [16][16]  rows of G = D^-1 U_jj (unit triangular: the substitution's operand)
+    double *dvals = Gd + 256;             // [mp]      diagonal of U
     double *U = pl.U + ur.mat_off;
     const double *Kp = pl.K + ur.mat_off;   // every tile is first read from the K pool (all of them in step 0)
     double *V = pl.V + (size_t)ur.row_off * 16;
@@ -582,7 +682,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         double s[16], dk, rdk;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = Kp[(size_t)i * mp + lr];
-        int bad = diag_factor16(s, lr, &dk, &rdk);
+        int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
         publish(s, dk, rdk, 0, bad);
     }
     __syncthreads();
@@ -615,24 +715,23 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
                 const double *Cr = Csrc + (size_t)(16 * j) * mp + col;
 #pragma unroll
                 for (int a = 0; a < 16; ++a) x[a] = Cr[(size_t)a * mp];
-                // U_jj one column per lane (in each row of 16 lanes): U[c][a] reaches the FMA by DPP broadcast from
-                // lane a — 16 LDS reads up front instead of one per FMA
-                double uc[16], rdl = rdt[lr];
+                // G = D^-1 U_jj one column per lane (in each row of 16 lanes): G[c][a] reaches the FMA by DPP broadcast from
+                // lane a — 16 LDS reads up front instead of one per FMA; unit triangular: the scaling by 1 / U_cc follows
+                // the substitution, off its chain
+                double uc[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) uc[c] = Ud[c * 16 + lr];
+                for (int c = 0; c < 16; ++c) uc[c] = Gd[c * 16 + lr];
                 static_for<0, 16>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
-                    x[c] *= bcast16<c>(rdl);
-                    static_for<c + 1, 16>([&](auto ac) {
+                    if constexpr (c + 1 < 16) fnma_bcast16_ordered<c + 1>(x[c + 1], uc[c], x[c]);
+                    double xs_ = x[c] * rdt[c];       // (1 / U_cc: a uniform LDS read)
+                    Cc[(size_t)c * mp] = xs_;
+                    P[c * ldp + col] = xs_;
+                    static_for<c + 2, 16>([&](auto ac) {
                         constexpr int a = decltype(ac)::value;
-                        fnma_bcast16<a>(x[a], uc[c], x[c]);
+                        fnma_bcast16_ordered<a>(x[a], uc[c], x[c]);
                     });
                 });
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    Cc[(size_t)a * mp] = x[a];
-                    P[a * ldp + col] = x[a];
-                }
             }
         }
         GPRF_STAMP(0)
@@ -656,7 +755,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
             double s[16], dk, rdk;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = Tt[r * 17 + lr];
-            int bad = diag_factor16(s, lr, &dk, &rdk);
+            int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
             publish(s, dk, rdk, i, bad);
         } else {
             // trailing update without tile (j+1,j+1): tile rows i = j+1 .. T-1 dealt cyclically to waves 1..7; along
@@ -875,7 +974,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
                                           // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
-    double *dvals = rdt + 16;             // [16 T]    diagonal of U
+    double *Gd = rdt + 16;                // [16][16]  rows of G = D^-1 U_jj (unit triangular: the substitution's operand)
+    double *dvals = Gd + 256;             // [16 T]    diagonal of U
     double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
     double *U = pl.U + ur.mat_off;
     const double *Kp = pl.K + ur.mat_off;   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
@@ -992,7 +1092,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = Dt[jt * 256 + r * 16 + lr];
 #ifndef GPRF_ABL_NOFACTOR
-        int bad = diag_factor16(s, lr, &dk, &rdk);
+        int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
 #else
         int bad = 0;
         dk = rdk = s[3];
@@ -1242,23 +1342,30 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                 double x[16];
 #pragma unroll
                 for (int a = 0; a < 16; ++a) x[a] = -P[a * ldp + col];   // the dump left minus the tile
-                double rdl = rdt[lr];
-                double uc[3] = {Ud[lr], Ud[16 + lr], 0.0};   // row c of U_jj, fetched two rows ahead
+                double uc[3] = {Gd[lr], Gd[16 + lr], 0.0};   // row c of G = D^-1 U_jj, fetched two rows ahead
+                double rc[3] = {rdt[0], rdt[1], 0.0};        // 1 / U_cc: the same for every lane (LDS broadcast read)
                 GPRF_STAMP2(1)
 #ifndef GPRF_ABL_NOSUBST
+                // unit triangular G: ONE fused multiply-add per step on the chain (row c+1 first); row c, final by now, is
+                // scaled by 1 / U_cc into a copy that goes straight to the panel — off the chain, between the other updates
                 static_for<0, 16>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
-                    if (c + 2 < 16) uc[(c + 2) % 3] = Ud[(c + 2) * 16 + lr];
-                    x[c] *= bcast16<c>(rdl);
-                    static_for<c + 1, 16>([&](auto ac) {
+                    if (c + 2 < 16) {
+                        uc[(c + 2) % 3] = Gd[(c + 2) * 16 + lr];
+                        rc[(c + 2) % 3] = rdt[c + 2];
+                    }
+                    if constexpr (c + 1 < 16) fnma_bcast16_ordered<c + 1>(x[c + 1], uc[c % 3], x[c]);
+                    P[c * ldp + col] = x[c] * rc[c % 3];
+                    static_for<c + 2, 16>([&](auto ac) {
                         constexpr int a = decltype(ac)::value;
-                        fnma_bcast16<a>(x[a], uc[c % 3], x[c]);
+                        fnma_bcast16_ordered<a>(x[a], uc[c % 3], x[c]);
                     });
                 });
-#endif
-                GPRF_STAMP2(2)
+#else
 #pragma unroll
                 for (int a = 0; a < 16; ++a) P[a * ldp + col] = x[a];
+#endif
+                GPRF_STAMP2(2)
               }
             }
         }
@@ -3017,7 +3124,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
-        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
         if (gen && ut.max_T <= reg_maxT) {
             lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
             // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the
@@ -3046,7 +3153,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
                 // larger ones one to a CU; each skips the other's units
                 int capS = POTRF_SMALL_MAXT;
-                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
+                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
                 if (lds_needs_optin(3, ldsS))
                     (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
@@ -3109,7 +3216,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 return;
             }
             if (ut.max_T <= POTRF_SMALL_MAXT && dual) {
-                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
+                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
                 if (lds_needs_optin(3, ldsS))
                     (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
@@ -3132,7 +3239,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                            stamps, reg_maxT, kp, 0);
         if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
     }
-    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 16 * ut.max_T) * sizeof(double);
+    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 256 + 16 * ut.max_T) * sizeof(double);
     if (lds_needs_optin(1, lds))
         (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, stamps, reg_maxT);
