@@ -37,7 +37,18 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak (vendor data sheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): clock under load
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+STAGE_PASS_EVALS = 60     # evaluations of the separate pass that times every kernel of every evaluation
+
+
+def source_hash():
+    """sha256 over the native sources: a committed rocprofv3 traffic figure counts for THIS code only if it was profiled
+    on the same sources (the GPU box has no git to ask)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gprf_amd/csrc/gprf_kernels.hip", "gprf_amd/csrc/gprf_capi.hip", "gprf_amd/csrc/gprf_kernels.h", "include/gprf_hip.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -55,11 +66,13 @@ def parse():
     ap.add_argument("--distinct-x", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the BASELINE configs[3] leg (n=80000)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE configs[4]-shaped leg (seismic stand-in, n=20000)")
     ap.add_argument("--only-north-star", action="store_true",
                     help="profiling runs: skip the secondary legs so that every kernel launch of the process has the "
                          "north-star shapes")
     ap.add_argument("--no-stage-timing", action="store_true",
-                    help="diagnostic: no HIP events between the kernels in the timed region (no roofline then)")
+                    help="diagnostic: skip the separate per-kernel timing pass (no roofline then)")
+    ap.add_argument("--source-hash", action="store_true", help="print the native sources' hash (profile_run.sh) and exit")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     return ap.parse_args()
 
@@ -196,11 +209,11 @@ def git_head():
         return None
 
 
-TIMING_PERIOD = 7
-
-
 def main():
     args = parse()
+    if args.source_hash:
+        print(source_hash())
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,8 +268,9 @@ def main():
         sd.set_centers(grid_centers(nblocks))
         return sd
 
-    def sequential_rate(g, Xlist, steps, warmup, grad_cov, timing_period=0):
-        """THE metric's loop: update_X + llgrad, one evaluation finished before the next starts; -> (evals/s, ms)"""
+    def sequential_rate(g, Xlist, steps, warmup, grad_cov):
+        """THE metric's loop: update_X + llgrad, one evaluation finished before the next starts, nothing else in the
+        timed region (no events); -> (evals/s, ms)"""
         nXl = len(Xlist)
         for k in range(warmup):
             g.update_X(Xlist[k % nXl])
@@ -264,13 +278,8 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for k in range(steps):
-            sampled = timing_period and k % timing_period == 0
-            if sampled:
-                g._ctx.set_timing(True)
             g.update_X(Xlist[k % nXl])
             g.llgrad(grad_X=True, grad_cov=grad_cov)
-            if sampled:
-                g._ctx.set_timing(False)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -320,21 +329,27 @@ def main():
 
     # ---------------- the timed region: the reference's GPRF object, sharded over the ranks
     g = sd.build_gprf(local_dist=args.local_dist, device=local_rank, shard=(rank, world))
-    g._ctx.set_timing(True, reset=True)
-    g._ctx.set_timing(False)
-    value, ms_per_step = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov,
-                                         0 if args.no_stage_timing else TIMING_PERIOD)
+    value, ms_per_step = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov)
     if args.no_stage_timing:
         if rank == 0:
-            print(json.dumps({"diagnostic": "no HIP events between kernels in the timed region", "value": value,
+            print(json.dumps({"diagnostic": "headline only (no per-kernel timing pass)", "value": value,
                               "unit": "evals/s", "ms_per_step": ms_per_step, "n_gpus": world}))
         g.close()
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
-    # per-stage averages over the timed region (HIP events on the launch stream), this rank's shard
+    # per-kernel durations: a SEPARATE pass of the same sequential loop with HIP events between the kernels of EVERY
+    # evaluation (recorded on the stream the kernels are launched on); the headline above carries none of it
+    g._ctx.set_timing(True, reset=True)
+    t_ev0 = time.perf_counter()
+    for k in range(STAGE_PASS_EVALS):
+        g.update_X(Xlist[k % nX])
+        g.llgrad(grad_X=True, grad_cov=grad_cov)
+    barrier()
+    ms_with_events = 1e3 * (time.perf_counter() - t_ev0) / STAGE_PASS_EVALS
     tm = g._ctx.get_timing()
+    g._ctx.set_timing(False)
     cnt = tm.pop("count")
     stage = dict(tm)
 
@@ -349,6 +364,7 @@ def main():
                 fl[a] = fl.get(a, 0.0) + b / nX
         total_all = float(np.mean([algorithmic_flops(s, args.yd)["total"] for s in sizes_all]))
         compute_stages = ["potrf", "solve", "at", "grad"]
+        # fixed rule: the dominant kernel is the LONGEST stage of the per-kernel timing pass
         dom = max(compute_stages + ["fill"], key=lambda s: stage[s])
         if dom == "fill":
             ach = fl["fill_bytes"] / (stage["fill"] * 1e-3) / 1e9
@@ -360,15 +376,20 @@ def main():
                     "frac": ach / FP64_PEAK_TFLOPS, "traffic": None}
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of this
         # same command; (2*FETCH_SIZE + WRITE_SIZE) KiB, read side doubled as the guide prescribes for gfx950)
+        # (traffic: only when the committed profile was taken on exactly these native sources — otherwise null and why)
         try:
             tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             key = {"potrf": "k_potrf_dual", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
-                roof["traffic"] = tr[key]["bytes_per_launch"]
-                roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), profiled at commit %s; this run: %s" % (
-                    TRAFFIC_FILE, tr.get("commit", "?"), git_head() or "no git on this box")
-        except Exception:
-            pass
+                if tr.get("source_hash") == source_hash():
+                    roof["traffic"] = tr[key]["bytes_per_launch"]
+                    roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these sources, hash %s)" % (
+                        TRAFFIC_FILE, tr.get("source_hash"))
+                else:
+                    roof["traffic_source"] = "null: %s was profiled on other sources (hash %s, commit %s; these: %s)" % (
+                        TRAFFIC_FILE, tr.get("source_hash"), tr.get("commit", "?"), source_hash())
+        except Exception as e:
+            roof["traffic_source"] = "null: %r" % (e,)
         roof["avg_launch_ms"] = stage[dom]
         roof["algorithmic_per_launch"] = fl["fill_bytes"] if dom == "fill" else fl[dom]
         # the Cholesky and the gradient stage are within a few per cent of each other: the same figures for every compute
@@ -376,6 +397,8 @@ def main():
         roof["all_stages"] = {s_: {"ms": round(stage[s_], 5), "TFLOPs": round(fl[s_] / (stage[s_] * 1e-3) / 1e12, 3),
                                    "frac": round(fl[s_] / (stage[s_] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)}
                               for s_ in compute_stages if stage[s_] > 0}
+        wk = min(roof["all_stages"], key=lambda s_: roof["all_stages"][s_]["frac"])
+        roof["worst"] = {"kernel": "k_" + wk, "frac": roof["all_stages"][wk]["frac"]}
         roof["mfma_f64_measured_peak"] = FP64_MFMA_MEASURED_TFLOPS
         kernels_ms = sum(stage[s] for s in stage)
         roof["whole_eval_TFLOPs_kernels"] = total_all / (kernels_ms * 1e-3) / 1e12 if world == 1 else None
@@ -396,8 +419,10 @@ def main():
             **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks time-share one GPU over gloo; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
             "kernels_ms_per_eval": round(kernels_ms, 5),
-            "stage_timing": "HIP events between the kernels on every %d-th evaluation of the timed region (%d sampled); "
-                            "'gather' includes the re-partition and table-build kernels" % (TIMING_PERIOD, cnt),
+            "stage_timing": "separate pass behind the timed region: %d sequential evaluations with HIP events between the kernels "
+                            "of every one (%.4f ms per evaluation with the events; the headline has none); 'gather' includes "
+                            "the re-partition and table-build kernels" % (cnt, ms_with_events),
+            "host_gap_ms": round(ms_per_step - kernels_ms, 5),
         }
 
     # ---------------- secondary figures
@@ -472,6 +497,41 @@ def main():
                             "algorithmic_TFLOPs": algorithmic_flops(s4, 50)["total"] * c4 / 1e12}
         g4.close()
         del sd4
+
+    # ---------------- BASELINE configs[4]'s shape on the stand-in catalogue (the ISC file is not distributed): great-circle /
+    # depth distance, Matern-3/2, split-tree blocks of < 210 events, edge threshold 0.6, task xcov; same sequential loop
+    # (update_X re-routes every event through the tree on the device)
+    if not args.only_north_star and not args.no_c5 and args.ntrain == 10000:
+        from gprf_amd import GPCov, seismic
+        n5 = 20000
+        X5 = seismic.synthetic_events(n5, seed=0)
+        Y5 = np.random.RandomState(1).randn(n5, 50)
+        blocks5, reblock5 = seismic.pdtree_cluster(X5, 210)
+        g5 = GPRF(X5, Y5, reblock5, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6,
+                  device=local_rank, shard=(rank, world))
+        rng5 = np.random.RandomState(2)
+        X5s = [np.ascontiguousarray(X5 + 1e-4 * k * rng5.randn(*X5.shape)) for k in range(3)]
+        c5, c5ms = sequential_rate(g5, X5s, 40, 5, True)
+        g5._ctx.set_timing(True, reset=True)
+        for k in range(12):
+            g5.update_X(X5s[k % 3])
+            g5.llgrad(grad_X=True, grad_cov=True)
+        barrier()
+        st5 = g5._ctx.get_timing()
+        g5._ctx.set_timing(False)
+        st5.pop("count")
+        if rank == 0:
+            sz5 = gdist.unit_sizes(g5.block_idxs, g5.neighbors)
+            fl5 = algorithmic_flops(sz5, 50)
+            result["c5_evals_per_s"] = c5
+            result["c5"] = {"workload": "STAND-IN catalogue (synthetic_events, n=%d), lld / matern32, split-tree blocks < 210 (%d blocks), "
+                                        "threshold 0.6 (%d pairs, largest unit %d points), yd=50, task xcov" % (
+                                            n5, len(g5.block_idxs), len(g5.neighbors), int(sz5.max())),
+                            "ms_per_eval": c5ms, "steps": 40, "distinct_X": 3,
+                            "stages_ms": {k2: round(v, 5) for k2, v in st5.items()},
+                            "algorithmic_TFLOPs": fl5["total"] * c5 / 1e12,
+                            "fill_GBps": (fl5["fill_bytes"] / (st5["fill"] * 1e-3) / 1e9) if (world == 1 and st5["fill"] > 0) else None}
+        g5.close()
 
     if world == 1 and not args.only_north_star and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, args.local_dist, args.cpu_seconds, grad_cov)

@@ -621,7 +621,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
-    if (!gen) launch_fill(c->dist_id, c->kern_id, ut, pl, kp, s);
+    launch_fill(c->dist_id, c->kern_id, ut, pl, kp, gen ? potrf_gen_maxT() : 0, s);
     mark();
     if (stop_after >= 1) {
         SideQueue side;
@@ -636,7 +636,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     if (stop_after >= 3) launch_at(ut, pl, s);
     mark();
     if (do_grad) {
-        launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);
+        launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
         launch_gx_finalize(ut, pl, kp, want_gc, s);
     }
     mark();

@@ -171,8 +171,12 @@ void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epo
 // every evaluation: coordinates into the unit rows (+ positions and unit row -> point when rebuilding)
 void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, int from_chunks, int force, int epoch,
                       hipStream_t s);
-void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
+// skip_T: units of at most that many tiles per edge are not filled (0 = all)
+void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int skip_T, hipStream_t s);
+// whether the register-resident Cholesky generates the kernel matrices of its units (at most potrf_gen_maxT() tiles per
+// edge) itself; larger units are filled into the K pool and factored by the generic kernel
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
+int potrf_gen_maxT();
 bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
 int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
 // The second queue for the instantiation that runs beside the main one, and how the two queues wait for each other:

@@ -317,14 +317,17 @@ template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = G
 // k_fill: the same fill by symmetry — one workgroup per 64x64 tile pair (ti <= tj): evaluates the tile once
 // (lane = column: 512-B wave stores), mirrors it through LDS and writes the transposed tile with the same
 // coalescing.  Halves the exp() work; the bytes written stay 8 mp^2 per unit.
+// skip_T: units of at most skip_T tiles per edge are left alone (the register-resident Cholesky generates their kernel
+// matrices itself; 0 = fill every unit)
 template <int DIST, int KERN>
-__global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp) {
+__global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int skip_T) {
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
     __shared__ double xr[64 * XS];
     const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
     int u = ur.u;
     int m = ur.m;
     int mp = pad16(m);
+    if ((mp >> 4) <= skip_T) return;
     int nt = (mp + 63) >> 6;
     int pidx = blockIdx.x;
     if (pidx >= nt * (nt + 1) / 2) return;
@@ -3075,20 +3078,23 @@ void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, 
                        force, epoch);
 }
 
-void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
-    if (ut.n_ids == 0 || ut.max_T == 0) return;
+void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int skip_T, hipStream_t s) {
+    if (ut.n_ids == 0 || ut.max_T == 0 || ut.max_T <= skip_T) return;
     int nt = (16 * ut.max_T + 63) / 64;
     dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
-    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp);
-    else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp);
+    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
+    else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
 }
 
 constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGPRs + 256 AGPRs each
 constexpr int POTRF_REG_SLOTS = 32;   // 3 workers x 32 slots >= 14*13/2 strictly-upper tiles (all 256 AGPRs)
 constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 points
 
-// true when launch_potrf(.., gen_ok = true) will generate the kernel matrices inside k_potrf_reg: every unit of the
-// launch takes the register-resident kernel (SE kernel only).  The caller then skips k_fill and tells k_mgrad.
+// Where a unit's kernel matrix comes from is decided PER UNIT: units of at most potrf_gen_maxT() tiles per edge (256
+// points) have it generated inside the register-resident Cholesky (SE kernel) — k_fill skips them and K never exists in
+// HBM for them — larger ones are filled into the K pool and factored by the generic kernel.  (Round 2 decided per
+// launch: one pair growing past 256 points during an optimisation sent all 442 units of the north-star configuration
+// through the K pool: +36 us fill, +12 us in the Cholesky.)  k_mgrad re-evaluates the values it needs in both cases.
 static bool potrf_use_reg(const UnitTab &ut) {
     const char *rg = getenv("GPRF_POTRF_REG");
     // (round 1's rule "at most 4 units per CU, else the generic two-per-CU kernel" predates the two-per-CU register
@@ -3100,8 +3106,9 @@ static bool potrf_use_reg(const UnitTab &ut) {
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
     const bool off = e && e[0] == '0';
-    return !off && dist_id == 0 && kern_id == 0 && ut.n_ids > 0 && ut.max_T <= POTRF_REG_MAXT_C && potrf_use_reg(ut);
+    return !off && dist_id == 0 && kern_id == 0 && ut.n_ids > 0 && potrf_use_reg(ut);
 }
+int potrf_gen_maxT() { return POTRF_REG_MAXT_C; }
 
 constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
 constexpr int POTRF_SMALL_MAXT = 13;
@@ -3122,10 +3129,18 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
     bool use_reg = potrf_use_reg(ut);
     int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
+    // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
+    auto launch_generic = [&]() {
+        if (ut.max_T <= reg_maxT) return;
+        size_t ldsg = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 256 + 16 * ut.max_T) * sizeof(double);
+        if (lds_needs_optin(1, ldsg))
+            (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+        hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), ldsg, s, ut, p, stamps, reg_maxT);
+    };
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
-        if (gen && ut.max_T <= reg_maxT) {
+        if (gen) {
             lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
             // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the
             // profiler then serialises the dispatches of ALL queues, and the stream-memory-operation wait that joins the two
@@ -3213,6 +3228,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                         (void)hipStreamWaitEvent(s, side.ev_join, 0);
                     }
                 }
+                launch_generic();
                 return;
             }
             if (ut.max_T <= POTRF_SMALL_MAXT && dual) {
@@ -3222,13 +3238,14 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
                 hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.n_ids),
                                    dim3(POTRF_REG_WAVES * 64), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
-                return;
+                return;      // (every unit has at most 13 tiles here)
             }
             if (lds_needs_optin(2, lds))
                 (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.n_ids),
                                dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 0);
+            launch_generic();
             return;
         }
         if (lds_needs_optin(0, lds))
@@ -3237,12 +3254,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
                            ut, p,
                            stamps, reg_maxT, kp, 0);
-        if (ut.max_T <= reg_maxT) return;   // nothing left for the generic kernel
     }
-    size_t lds = (size_t)(16 * (16 * ut.max_T + 16) + 256 + 16 + 16 * 17 + 256 + 16 * ut.max_T) * sizeof(double);
-    if (lds_needs_optin(1, lds))
-        (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), lds, s, ut, p, stamps, reg_maxT);
+    launch_generic();
 }
 
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {

@@ -17,7 +17,7 @@ nt, nl = ctx.num_units()
 rows = np.array([ctx.debug_fetch(l, 6) for l in range(nl)])
 v3 = False
 tc = 7 if mode2 else (5 if v3 else 4)
-for T in (7, 13, 15, 16):
+for T in (7, 10, 12, 13, 14, 15, 16):
     sel = rows[rows[:, tc] == T]
     if len(sel):
         m = sel[:, :tc].mean(axis=0)

@@ -433,6 +433,42 @@ def test_generated_and_filled_kernel_matrices_give_the_same_evaluation(monkeypat
     assert _close(out["1"][1], out["0"][1], 1e-12) and np.allclose(out["1"][2], out["0"][2], rtol=1e-11)
 
 
+def test_one_pair_over_256_points_leaves_the_other_units_generated(monkeypatch):
+    """The kernel-matrix source is decided per unit (round 2 decided per launch: one pair growing past 256 points sent every
+    unit through the K pool).  A north-star-shaped partition in which ONE block is crowded so that its pairs exceed 256
+    points: those units take k_fill + the generic Cholesky, all others are generated inside the register-resident one; the
+    result equals the all-through-the-pool evaluation to rounding and the oracle's."""
+    from gprf_amd import Blocker, grid_centers, GPCov
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OCov
+    rng = np.random.RandomState(21)
+    n = 2500
+    X = rng.rand(n, 2)
+    c = np.array(grid_centers(25))
+    X[:110] = c[12] + 0.05 * (rng.rand(110, 2) - 0.5)        # the centre block gets ~210 points: its pairs 300+
+    Y = rng.randn(n, 6)
+    b = Blocker(c)
+    blocks, nbrs = b.block_clusters(X), b.neighbors()
+    sizes = np.array([len(v) for v in blocks])
+    pair_sizes = np.array([sizes[i] + sizes[j] for (i, j) in nbrs])
+    assert (pair_sizes > 256).sum() >= 4 and (pair_sizes <= 256).sum() > 40 and pair_sizes.max() <= 1024
+    cov = GPCov([1.0], [0.12, 0.12], "euclidean", "se")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPRF_FUSED_FILL", mode)
+        g = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=nbrs)
+        out[mode] = g.llgrad(grad_X=True, grad_cov=True)
+        g.close()
+    monkeypatch.delenv("GPRF_FUSED_FILL")
+    r = GPRFRef(X, Y, None, OCov([1.0], [0.12, 0.12], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs, mode="matrix")
+    o = r.llgrad(grad_X=True, grad_cov=True)
+    for mode in ("1", "0"):
+        assert np.isclose(out[mode][0], o[0], rtol=1e-12)
+        assert _close(out[mode][1], o[1], 1e-9) and np.allclose(out[mode][2], o[2], rtol=1e-8)
+    assert np.isclose(out["1"][0], out["0"][0], rtol=1e-13) and _close(out["1"][1], out["0"][1], 1e-11)
+
+
 def _unit_tables(g):
     ctx = g._ctx
     return [ctx.debug_fetch(l, 10) for l in range(ctx.num_units()[1])]
