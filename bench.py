@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--distinct-x", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the BASELINE configs[3] leg (n=80000)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the --gpus N devices from THIS one process (gprf_create_multi: no torchrun, no inter-process "
+                         "collective) — the shape of the reference's own single-process drivers")
     ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE configs[4]-shaped leg (seismic stand-in, n=20000)")
     ap.add_argument("--only-north-star", action="store_true",
                     help="profiling runs: skip the secondary legs so that every kernel launch of the process has the "
@@ -217,7 +220,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    devices = None
+    if args.single_process:
+        if world != 1:
+            sys.exit("bench.py --single-process runs as ONE process (no torch.distributed.run)")
+        # (GPRF_BENCH_ONE_GPU=1: N logical members on GPU 0 — exercises the path on a one-GPU box, the numbers mean nothing)
+        devices = [0] * args.gpus if os.environ.get("GPRF_BENCH_ONE_GPU") == "1" else list(range(args.gpus))
+    elif world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
@@ -328,7 +337,8 @@ def main():
     sizes_all = [gdist.unit_sizes(sd.reblock(Xs[k]), nbrs) for k in range(nX)]
 
     # ---------------- the timed region: the reference's GPRF object, sharded over the ranks
-    g = sd.build_gprf(local_dist=args.local_dist, device=local_rank, shard=(rank, world))
+    g = (sd.build_gprf(local_dist=args.local_dist, devices=devices) if devices is not None else
+         sd.build_gprf(local_dist=args.local_dist, device=local_rank, shard=(rank, world)))
     value, ms_per_step = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov)
     if args.no_stage_timing:
         if rank == 0:
@@ -358,7 +368,7 @@ def main():
         # algorithmic work of this rank's shard, averaged over the distinct X
         fl = {}
         for k in range(nX):
-            owner = _capi.partition_units(sizes_all[k], args.yd, world)
+            owner = _capi.partition_units(sizes_all[k], args.yd, len(devices) if devices is not None else world)
             f_ = algorithmic_flops(sizes_all[k][owner == 0], args.yd)
             for a, b in f_.items():
                 fl[a] = fl.get(a, 0.0) + b / nX
@@ -405,7 +415,7 @@ def main():
         roof["whole_eval_frac_of_fp64_peak_kernels"] = (total_all / (kernels_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if world == 1 else None
         result = {
             "metric": "GPRF objective+gradient evals/sec, n=%d nblocks=%d yd=%d" % (ntrain, args.nblocks, args.yd),
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": len(devices) if devices is not None else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "n=%d nblocks=%d yd=%d lscale=%g obs_std=%g local_dist=%g (%d unary + %d pair units) task=%s"
@@ -414,9 +424,11 @@ def main():
                        "distinct_X": nX,
                        "step": "host X in -> update_X (device re-partition + table rebuild) -> llgrad -> host result out, "
                                "sequential, one synchronisation per evaluation",
-                       "parallelism": "units sharded over %d rank(s), 1 all-reduce/eval" % world},
+                       "parallelism": ("units sharded over %d device(s) driven by ONE process; partial sums meet on device 0 (peer "
+                                       "stores + one summing kernel)" % len(devices)) if devices is not None else
+                                      "units sharded over %d rank(s), 1 all-reduce/eval" % world},
             "roofline": roof,
-            **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks time-share one GPU over gloo; not a measurement"} if one_gpu else {}),
+            **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks / members time-share one GPU; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
             "kernels_ms_per_eval": round(kernels_ms, 5),
             "stage_timing": "separate pass behind the timed region: %d sequential evaluations with HIP events between the kernels "
@@ -484,7 +496,8 @@ def main():
     # ---------------- BASELINE configs[3] (n=80000, 841 blocks + 3192 pairs, task xcov), same sequential loop, every N
     if not args.only_north_star and not args.no_c4 and args.ntrain == 10000:
         sd4 = sample(80000, 0.02, 0.002, 800)
-        g4 = sd4.build_gprf(local_dist=0.5, device=local_rank, shard=(rank, world))
+        g4 = (sd4.build_gprf(local_dist=0.5, devices=devices) if devices is not None else
+              sd4.build_gprf(local_dist=0.5, device=local_rank, shard=(rank, world)))
         rng = np.random.RandomState(1)
         X4 = [np.ascontiguousarray(sd4.X_obs + 0.25 * sd4.obs_std * k * rng.randn(*sd4.X_obs.shape)) for k in range(3)]
         c4, c4ms = sequential_rate(g4, X4, 30, 5, True)
@@ -507,8 +520,8 @@ def main():
         X5 = seismic.synthetic_events(n5, seed=0)
         Y5 = np.random.RandomState(1).randn(n5, 50)
         blocks5, reblock5 = seismic.pdtree_cluster(X5, 210)
-        g5 = GPRF(X5, Y5, reblock5, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6,
-                  device=local_rank, shard=(rank, world))
+        kw5 = dict(devices=devices) if devices is not None else dict(device=local_rank, shard=(rank, world))
+        g5 = GPRF(X5, Y5, reblock5, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6, **kw5)
         rng5 = np.random.RandomState(2)
         X5s = [np.ascontiguousarray(X5 + 1e-4 * k * rng5.randn(*X5.shape)) for k in range(3)]
         c5, c5ms = sequential_rate(g5, X5s, 40, 5, True)

@@ -25,6 +25,7 @@ _i32 = ctypes.c_int32
 # every entry point include/gprf_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "gprf_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32]),
+    "gprf_create_multi": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32p]),
     "gprf_destroy": (ctypes.c_int, [_vp]),
     "gprf_last_error": (ctypes.c_char_p, [_vp]),
     "gprf_set_Y": (ctypes.c_int, [_vp, _dp]),
@@ -199,14 +200,21 @@ def hyper_grad(mode, cov_scale, prior_mean, prior_std, zh, gradC):
 class Context(object):
     """Thin RAII wrapper over gprf_ctx*."""
 
-    def __init__(self, n, dx, dy, dist_id, kern_id, device=0):
+    def __init__(self, n, dx, dy, dist_id, kern_id, device=0, devices=None):
+        """``devices``: a list of HIP device ordinals -> one context over several devices, driven from this one process
+        (gprf_create_multi); otherwise ``device``."""
         self.lib = load()
         self.h = _vp()
-        rc = self.lib.gprf_create(ctypes.byref(self.h), n, dx, dy, dist_id, kern_id, device)
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            rc = self.lib.gprf_create_multi(ctypes.byref(self.h), n, dx, dy, dist_id, kern_id, len(devs), devs.ctypes.data_as(_i32p))
+        else:
+            rc = self.lib.gprf_create(ctypes.byref(self.h), n, dx, dy, dist_id, kern_id, device)
         if rc != GPRF_OK:
             self.h = None
-            raise GprfHipError("gprf_create failed (%d): no usable HIP device %d, or unsupported "
-                               "shape/kernel (n=%d dx=%d dy=%d dist=%d kern=%d)" % (rc, device, n, dx, dy, dist_id, kern_id))
+            raise GprfHipError("gprf_create failed (%d): no usable HIP device %s, or unsupported "
+                               "shape/kernel (n=%d dx=%d dy=%d dist=%d kern=%d)" % (rc, devices if devices is not None else device,
+                                                                                 n, dx, dy, dist_id, kern_id))
         self.n, self.dx, self.dy = n, dx, dy
         self.ncov = 2 + (dx if dist_id == 0 else 2)
 

@@ -61,7 +61,8 @@ struct PinBuf {
         size_t want = n + n / 4 + 64;
         // pinned, mapped into the device's address space, coherent (fine-grained): what a kernel wrote is visible to
         // the host once the stream has been synchronised
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
+        // (portable: a multi-device group's members on other devices read / write the front context's buffers)
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
         if (e != hipSuccess) return e;
         e = hipHostGetDevicePointer((void **)&d, (void *)p, 0);
         if (e != hipSuccess) { (void)hipHostFree(p); p = d = nullptr; return e; }
@@ -153,6 +154,16 @@ struct gprf_ctx {
     int hyper_mode = 0;                   // GPRF_HYPER_NONE / TIED / FULL
     double cov_scale = 1.0, hp_mean = 0.0, hp_std = 1.0, fixed_nv = 0.0, fixed_sv = 1.0;
     bool objective_call = false;          // the evaluation being enqueued leaves in the optimiser's form
+
+    // single-process multi-device group (gprf_create_multi): this context is the FRONT of kids.size() member contexts, one
+    // per (logical) device, member k evaluating shard (k, N) of the units; the members' assembly kernels write their
+    // partial vectors into slots in the front device's memory, k_sum_parts adds them into the front's pinned host vector
+    std::vector<gprf_ctx *> kids;
+    std::vector<double> h_Xobs_front;     // the front's copy of the prior means (gprf_objective's parts_out)
+    DevBuf<double> d_slots;
+    size_t slot_stride = 0;
+    hipStream_t red_stream = nullptr;
+    std::vector<hipEvent_t> ev_kid;
 
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
@@ -513,6 +524,11 @@ int upload_host_partition(gprf_ctx *c, hipStream_t s) {
 
 int check_ready(gprf_ctx *c) {
     if (!c) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {
+        int rc = check_ready(c->kids[0]);
+        if (rc != GPRF_OK) c->err = c->kids[0]->err;
+        return rc;
+    }
     if (!c->have_Y) return fail(c, GPRF_ERR_STATE, "gprf_set_Y has not been called");
     if (!c->have_theta) return fail(c, GPRF_ERR_STATE, "gprf_set_theta has not been called");
     if (!c->have_blocks) return fail(c, GPRF_ERR_STATE, "gprf_set_blocks has not been called");
@@ -788,9 +804,101 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
     return GPRF_OK;
 }
 
+// every member: the call, first failure reported through the front context
+#define GROUP_BROADCAST(c, call)                                        \
+    if (!(c)->kids.empty()) {                                           \
+        for (gprf_ctx *k : (c)->kids) {                                 \
+            int rc__ = (call);                                          \
+            if (rc__ != GPRF_OK) { (c)->err = k->err; return rc__; }    \
+        }                                                               \
+    }
+
+#define GROUP_FORWARD(c, call)                                          \
+    if ((c) && !(c)->kids.empty()) {                                    \
+        GROUP_BROADCAST(c, call)                                        \
+        return GPRF_OK;                                                 \
+    }
+#define GROUP_REFUSE(c, what)                                           \
+    if ((c) && !(c)->kids.empty())                                      \
+        return fail((c), GPRF_ERR_STATE, what " is not available on a multi-device group (it evaluates through gprf_eval / gprf_update_eval / gprf_objective)");
+
+// One evaluation over a multi-device group, driven from this one host thread (the reference's single-process drivers,
+// gprfopt.py:377-422, with the fan-out inside llgrad, gprf.py:218-233): X once into the front's pinned buffer, which every
+// member's kernels read; every member enqueues its shard on its own device and stream, its assembly kernel storing the
+// partial vector into its slot on the front device; k_sum_parts behind all of them; one completion flag.
+int group_run(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll_out, double *gradX_out, double *gradC_out,
+              int32_t *first_bad_unit, bool reblock, int32_t *reblocked, bool objective) {
+    const int N = (int)c->kids.size();
+    size_t nx = (size_t)c->n * c->dx;
+    size_t nout = 1 + nx + c->ncov + 2;
+    memcpy(c->h_X.p, X, nx * sizeof(double));
+    int any_reblocked = 0;
+    if (first_bad_unit) *first_bad_unit = -1;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        for (int k = 0; k < N; ++k) {
+            gprf_ctx *m = c->kids[k];
+            HIP_TRY(c, hipSetDevice(m->device));
+            m->objective_call = objective;
+            int rc = enqueue_eval(m, c->h_X.d, want_gx, want_gc, c->d_slots.p + (size_t)k * c->slot_stride, m->stream, 6, reblock);
+            m->objective_call = false;
+            if (rc != GPRF_OK) { c->err = m->err; return rc; }
+            HIP_TRY(c, hipEventRecord(c->ev_kid[k], m->stream));
+        }
+        HIP_TRY(c, hipSetDevice(c->device));
+        for (int k = 0; k < N; ++k) HIP_TRY(c, hipStreamWaitEvent(c->red_stream, c->ev_kid[k], 0));
+        launch_sum_parts(c->d_slots.p, N, c->slot_stride, nout, c->h_out.d, c->red_stream);
+        c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
+        launch_done(c->h_done.d, c->done_seq, c->red_stream);
+        HIP_TRY(c, hipGetLastError());
+        {   // the front's completion flag (bounded wait, like finish_eval)
+            volatile int32_t *flag = c->h_done.p;
+            auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (*flag != c->done_seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+                    int rc = bounded_stream_wait(c, c->red_stream);
+                    if (rc != GPRF_OK) return rc;
+                    break;
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        // every member's own status (its stream is complete: the reduction waited for it)
+        int worst = GPRF_OK, bad = -1;
+        for (int k = 0; k < N; ++k) {
+            gprf_ctx *m = c->kids[k];
+            HIP_TRY(c, hipSetDevice(m->device));
+            int32_t b = -1, rb = 0;
+            int rc = finish_eval(m, m->stream, &b, &rb);
+            any_reblocked |= rb;
+            if (rc < 0) { c->err = m->err; return rc; }
+            if (rc == GPRF_RETRY) worst = GPRF_RETRY;
+            if (rc == GPRF_NOT_PD) {
+                if (worst != GPRF_RETRY) worst = GPRF_NOT_PD;
+                if (bad < 0 || b < bad) { bad = b; c->err = m->err; }
+            }
+        }
+        if (worst == GPRF_RETRY) { reblock = false; continue; }      // the outgrown members have grown: everybody once more
+        if (reblocked) *reblocked = any_reblocked;
+        c->last_reblocked = any_reblocked != 0;
+        if (worst == GPRF_NOT_PD) {
+            if (first_bad_unit) *first_bad_unit = bad;
+            return GPRF_NOT_PD;
+        }
+        *ll_out = c->h_out.p[0];
+        if (want_gx) memcpy(gradX_out, c->h_out.p + 1, nx * sizeof(double));
+        if (want_gc) memcpy(gradC_out, c->h_out.p + 1 + nx, c->ncov * sizeof(double));
+        return GPRF_OK;
+    }
+    return fail(c, GPRF_ERR_STATE, "the unit tables did not fit the workspace after growing it twice");
+}
+
 // host X in -> host result out, optionally re-partitioning first; repeats when the workspace had to grow
 int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll_out, double *gradX_out,
                 double *gradC_out, int32_t *first_bad_unit, bool reblock, int32_t *reblocked, bool objective = false) {
+    if (!c->kids.empty())
+        return group_run(c, X, want_gx, want_gc, ll_out, gradX_out, gradC_out, first_bad_unit, reblock, reblocked, objective);
     hipStream_t s = c->stream;
     size_t nx = (size_t)c->n * c->dx;
     size_t nout = 1 + nx + c->ncov + 2;
@@ -883,9 +991,52 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     return GPRF_OK;
 }
 
+int gprf_create_multi(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
+                      int32_t n_devices, const int32_t *devices) {
+    if (!out) return GPRF_ERR_ARG;
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64 || !devices) return GPRF_ERR_ARG;
+    gprf_ctx *c = nullptr;
+    int rc = gprf_create(&c, n, dx, dy, dist_id, kern_id, devices[0]);
+    if (rc != GPRF_OK) return rc;
+    size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
+    c->slot_stride = (nout + 31) & ~(size_t)31;
+    bool ok = hipSetDevice(devices[0]) == hipSuccess && c->d_slots.reserve(c->slot_stride * n_devices + 32, 1.0) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < n_devices; ++k) {
+        gprf_ctx *m = nullptr;
+        ok = gprf_create(&m, n, dx, dy, dist_id, kern_id, devices[k]) == GPRF_OK;
+        if (!ok) break;
+        c->kids.push_back(m);
+        m->rank = k;
+        m->world = n_devices;
+        hipEvent_t ev = nullptr;
+        ok = hipSetDevice(devices[k]) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) c->ev_kid.push_back(ev);
+        // the member's assembly kernel stores into the front device's memory
+        if (ok && devices[k] != devices[0]) {
+            int can = 0;
+            ok = hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can;
+            if (ok) {
+                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    if (!ok) { gprf_destroy(c); return GPRF_ERR_HIP; }
+    *out = c;
+    return GPRF_OK;
+}
+
 int gprf_destroy(gprf_ctx *c) {
     if (!c) return GPRF_OK;
+    for (gprf_ctx *k : c->kids) (void)gprf_destroy(k);
+    c->kids.clear();
     (void)hipSetDevice(c->device);
+    if (c->red_stream) { (void)hipStreamSynchronize(c->red_stream); (void)hipStreamDestroy(c->red_stream); }
+    for (hipEvent_t e : c->ev_kid) (void)hipEventDestroy(e);
+    c->d_slots.release();
     if (c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
@@ -916,6 +1067,7 @@ const char *gprf_last_error(const gprf_ctx *c) { return c ? c->err.c_str() : "nu
 
 int gprf_set_Y(gprf_ctx *c, const double *Y) {
     if (!c || !Y) return GPRF_ERR_ARG;
+    GROUP_FORWARD(c, gprf_set_Y(k, Y))
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -931,11 +1083,13 @@ int gprf_set_theta(gprf_ctx *c, const double *theta, int32_t ntheta) {
         if (!std::isfinite(theta[i])) return fail(c, GPRF_ERR_ARG, "non-finite hyper-parameter");
     c->theta.assign(theta, theta + ntheta);
     c->have_theta = true;
+    GROUP_FORWARD(c, gprf_set_theta(k, theta, ntheta))
     return GPRF_OK;
 }
 
 int gprf_set_blocks(gprf_ctx *c, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx) {
     if (!c || n_blocks < 0 || !block_ptr) return GPRF_ERR_ARG;
+    GROUP_FORWARD(c, gprf_set_blocks(k, n_blocks, block_ptr, point_idx))
     if (block_ptr[0] != 0) return fail(c, GPRF_ERR_ARG, "block_ptr[0] must be 0");
     for (int b = 0; b < n_blocks; ++b)
         if (block_ptr[b + 1] < block_ptr[b]) return fail(c, GPRF_ERR_ARG, "block_ptr must be non-decreasing");
@@ -1045,6 +1199,8 @@ int gprf_set_block_assignment(gprf_ctx *c, int32_t n_blocks, const int32_t *bloc
 
 int gprf_set_centers(gprf_ctx *c, int32_t nc, const double *centers) {
     if (!c || nc < 1 || !centers) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) { c->n_centers = nc; c->tree_nodes = 0; }
+    GROUP_FORWARD(c, gprf_set_centers(k, nc, centers))
     HIP_TRY(c, hipSetDevice(c->device));
     int dx = c->dx;
     std::vector<double> c2(nc), cs((size_t)dx * nc);
@@ -1073,6 +1229,12 @@ int gprf_set_split_tree(gprf_ctx *c, int32_t n_nodes, int32_t dim, int32_t lon_w
                         const double *center, const double *split, const int32_t *left, const int32_t *right,
                         const int32_t *leaf_block) {
     if (!c || n_nodes < 1 || dim < 1 || !vec || !center || !split || !left || !right || !leaf_block) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {
+        GROUP_BROADCAST(c, gprf_set_split_tree(k, n_nodes, dim, lon_wrap, vec, center, split, left, right, leaf_block))
+        c->n_centers = c->kids[0]->n_centers;
+        c->tree_nodes = n_nodes;
+        return GPRF_OK;
+    }
     if (dim > c->dx || dim > 8) return fail(c, GPRF_ERR_ARG, "tree dimension exceeds the point dimension");
     // a well-formed tree: children point forward (so every descent ends), leaves carry distinct block ids 0..n_leaves-1
     int n_leaves = 0;
@@ -1111,6 +1273,15 @@ int gprf_set_split_tree(gprf_ctx *c, int32_t n_nodes, int32_t dim, int32_t lon_w
 
 int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *block_of_out) {
     if (!c || !X || !changed) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {      // every member holds the whole partition (its shard of the units is cut from it)
+        for (size_t k = 0; k < c->kids.size(); ++k) {
+            int32_t ch = 0;
+            int rc = gprf_assign_blocks(c->kids[k], X, &ch, k == 0 ? block_of_out : nullptr);
+            if (rc != GPRF_OK) { c->err = c->kids[k]->err; return rc; }
+            if (k == 0) *changed = ch;
+        }
+        return GPRF_OK;
+    }
     if (c->n_centers < 1) return fail(c, GPRF_ERR_STATE, "gprf_set_centers or gprf_set_split_tree first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->have_blocks || c->n_blocks != c->n_centers || (int)c->h_bsize.size() != c->n_centers) {
@@ -1156,6 +1327,7 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
 
 int gprf_get_block_assignment(gprf_ctx *c, int32_t *block_of_out) {
     if (!c || !block_of_out) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) return gprf_get_block_assignment(c->kids[0], block_of_out);
     HIP_TRY(c, hipSetDevice(c->device));
     return fetch_assignment(c, block_of_out);
 }
@@ -1163,6 +1335,11 @@ int gprf_get_block_assignment(gprf_ctx *c, int32_t *block_of_out) {
 int gprf_pair_kernel_max(gprf_ctx *c, const double *X, int32_t n_blocks, const int64_t *block_ptr, const int32_t *point_idx,
                          double threshold, int32_t n_cand, const int32_t *cand_ij, int32_t *keep_out, double *max_out) {
     if (!c || !X || n_blocks < 0 || !block_ptr || n_cand < 0 || (n_cand > 0 && (!cand_ij || !keep_out))) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {      // one-time setup work: the first member's device
+        int rc = gprf_pair_kernel_max(c->kids[0], X, n_blocks, block_ptr, point_idx, threshold, n_cand, cand_ij, keep_out, max_out);
+        if (rc != GPRF_OK) c->err = c->kids[0]->err;
+        return rc;
+    }
     if (!c->have_theta) return fail(c, GPRF_ERR_STATE, "gprf_set_theta has not been called");
     if (n_cand == 0) return GPRF_OK;
     int64_t tot = block_ptr[n_blocks];
@@ -1205,6 +1382,8 @@ int gprf_pair_kernel_max(gprf_ctx *c, const double *X, int32_t n_blocks, const i
 
 int gprf_set_neighbors(gprf_ctx *c, int32_t n_pairs, const int32_t *pairs_ij) {
     if (!c || n_pairs < 0 || (n_pairs > 0 && !pairs_ij)) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) c->n_pairs = n_pairs;
+    GROUP_FORWARD(c, gprf_set_neighbors(k, n_pairs, pairs_ij))
     c->n_pairs = n_pairs;
     c->pairs.assign(pairs_ij, pairs_ij + 2 * (size_t)n_pairs);
     c->static_dirty = true;
@@ -1231,6 +1410,7 @@ int gprf_partition_units(int32_t n_units, const int32_t *m, int32_t dy, int32_t 
 
 int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return GPRF_ERR_ARG;
+    GROUP_REFUSE(c, "gprf_set_shard")
     c->rank = rank;
     c->world = world;
     c->static_dirty = true;
@@ -1240,6 +1420,7 @@ int gprf_set_shard(gprf_ctx *c, int32_t rank, int32_t world) {
 
 int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
     if (!c) return GPRF_ERR_ARG;
+    GROUP_FORWARD(c, gprf_set_unit_jitter(k, n_units, jitter))
     if (!jitter) {
         // the drivers clear the jitter before every evaluation (jitchol is stateless): clearing what is already
         // clear costs nothing
@@ -1257,6 +1438,7 @@ int gprf_set_unit_jitter(gprf_ctx *c, int32_t n_units, const double *jitter) {
 
 int gprf_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
                      void *stream) {
+    GROUP_REFUSE(c, "gprf_eval_device")
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
     if (!d_X || !d_out) return GPRF_ERR_ARG;
@@ -1267,6 +1449,7 @@ int gprf_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t
 
 int gprf_update_eval_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
                             void *stream) {
+    GROUP_REFUSE(c, "gprf_update_eval_device")
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
     if (!d_X || !d_out) return GPRF_ERR_ARG;
@@ -1371,6 +1554,13 @@ int gprf_hyper_grad(int32_t mode, double cov_scale, double prior_mean, double pr
 
 int gprf_set_x_prior(gprf_ctx *c, const double *X_obs, double obs_std) {
     if (!c) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {      // the data lives with the members (the first adds the prior), the layout of z with the front
+        GROUP_BROADCAST(c, gprf_set_x_prior(k, X_obs, obs_std))
+        c->xprior = X_obs != nullptr;
+        c->obs_std = obs_std;
+        c->h_Xobs_front.assign(X_obs ? X_obs : nullptr, X_obs ? X_obs + (size_t)c->n * c->dx : nullptr);
+        return GPRF_OK;
+    }
     if (!X_obs) { c->xprior = false; return GPRF_OK; }
     if (!(obs_std > 0.0) || !std::isfinite(obs_std)) return fail(c, GPRF_ERR_ARG, "obs_std must be positive");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1393,6 +1583,7 @@ int gprf_set_hyper_param(gprf_ctx *c, int32_t mode, double cov_scale, double pri
         return fail(c, GPRF_ERR_ARG, "cov_scale and prior_std must be positive");
     c->hyper_mode = mode; c->cov_scale = cov_scale; c->hp_mean = prior_mean; c->hp_std = prior_std;
     c->fixed_nv = fixed_noise_var; c->fixed_sv = fixed_signal_var;
+    GROUP_FORWARD(c, gprf_set_hyper_param(k, mode, cov_scale, prior_mean, prior_std, fixed_noise_var, fixed_signal_var))
     return GPRF_OK;
 }
 
@@ -1430,12 +1621,23 @@ int gprf_objective(gprf_ctx *c, const double *z, int32_t nz, const double *X_fix
         f -= hp_ll;
     }
     *f_out = f;
-    if (parts_out) { parts_out[0] = c->h_out.p[nout]; parts_out[1] = c->h_out.p[nout + 1]; parts_out[2] = hp_ll; }
+    if (parts_out) {
+        if (c->kids.empty()) {
+            parts_out[0] = c->h_out.p[nout]; parts_out[1] = c->h_out.p[nout + 1];
+        } else {      // (a group's partial sums carry no split: the location prior again, on the host)
+            double xp = 0.0;
+            if (nx) (void)gprf_x_prior(nx, z, c->h_Xobs_front.data(), c->obs_std, &xp, nullptr);
+            parts_out[1] = xp;
+            parts_out[0] = -(f + hp_ll) - xp;
+        }
+        parts_out[2] = hp_ll;
+    }
     return GPRF_OK;
 }
 
 int gprf_objective_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, int32_t want_gradC, double *d_out,
                           void *stream, int32_t reblock) {
+    GROUP_REFUSE(c, "gprf_objective_device")
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
     if (!d_X || !d_out) return GPRF_ERR_ARG;
@@ -1450,6 +1652,16 @@ int gprf_objective_device(gprf_ctx *c, const double *d_X, int32_t want_gradX, in
 
 int gprf_num_units(const gprf_ctx *c, int32_t *n_total, int32_t *n_local) {
     if (!c) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) {
+        int32_t tot = 0, loc = 0, sum = 0;
+        for (const gprf_ctx *k : c->kids) {
+            (void)gprf_num_units(k, &tot, &loc);
+            sum = (loc < 0 || sum < 0) ? -1 : sum + loc;
+        }
+        if (n_total) *n_total = tot;
+        if (n_local) *n_local = sum;
+        return GPRF_OK;
+    }
     if (n_total) *n_total = c->n_blocks + c->n_pairs;
     if (n_local) *n_local = c->static_dirty ? -1 : c->n_local;
     return GPRF_OK;
@@ -1458,6 +1670,18 @@ int gprf_num_units(const gprf_ctx *c, int32_t *n_total, int32_t *n_local) {
 int gprf_work_estimate(gprf_ctx *c, double *flops, double *fill_bytes) {
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
+    if (!c->kids.empty()) {
+        double f = 0, b = 0;
+        for (gprf_ctx *k : c->kids) {
+            double fk = 0, bk = 0;
+            rc = gprf_work_estimate(k, &fk, &bk);
+            if (rc != GPRF_OK) { c->err = k->err; return rc; }
+            f += fk; b += bk;
+        }
+        if (flops) *flops = f;
+        if (fill_bytes) *fill_bytes = b;
+        return GPRF_OK;
+    }
     if (c->static_dirty) {
         HIP_TRY(c, hipSetDevice(c->device));
         rc = rebuild_static(c);
@@ -1528,6 +1752,7 @@ int gprf_last_reblocked(const gprf_ctx *c, int32_t *reblocked) {
 
 int gprf_table_builds(gprf_ctx *c, int32_t *builds) {
     if (!c || !builds) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) return gprf_table_builds(c->kids[0], builds);
     *builds = 0;
     if (!c->d_res.p) return GPRF_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1539,6 +1764,7 @@ int gprf_table_builds(gprf_ctx *c, int32_t *builds) {
 
 int gprf_set_timing(gprf_ctx *c, int32_t enable) {
     if (!c) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) return gprf_set_timing(c->kids[0], enable);      // (a group: the first member's kernels)
     c->timing = enable != 0;
     if (enable == 2) {  // reset the running totals
         if (c->ev_valid) {
@@ -1554,6 +1780,7 @@ int gprf_set_timing(gprf_ctx *c, int32_t enable) {
 
 int gprf_get_timing(gprf_ctx *c, int32_t n, double *ms_out) {
     if (!c || !ms_out || n < GPRF_N_STAGES) return GPRF_ERR_ARG;
+    if (!c->kids.empty()) return gprf_get_timing(c->kids[0], n, ms_out);
     if (!c->ev_valid || c->n_timed == 0) return fail(c, GPRF_ERR_STATE, "no timed evaluation yet");
     HIP_TRY(c, hipSetDevice(c->device));
     for (int r = 0; r < gprf_ctx::RING; ++r)
@@ -1567,6 +1794,7 @@ int gprf_get_timing(gprf_ctx *c, int32_t n, double *ms_out) {
 }
 
 int gprf_debug_run(gprf_ctx *c, const double *X, int32_t stop_after) {
+    GROUP_REFUSE(c, "gprf_debug_run")
     int rc = check_ready(c);
     if (rc != GPRF_OK) return rc;
     if (!X) return GPRF_ERR_ARG;

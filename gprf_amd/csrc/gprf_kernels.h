@@ -199,6 +199,8 @@ void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, c
 void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, double *extras, int32_t *flag, int32_t seq,
                    hipStream_t s);
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s);
+// out[i] = sum over the n_parts partial vectors slots[k * stride + i], in member order
+void launch_sum_parts(const double *slots, int n_parts, size_t stride, size_t nvec, double *out, hipStream_t s);
 // threshold neighbour discovery: keep[c] = max |k| / sv over candidate block pair c > thr (early out unless want_max)
 void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const int64_t *blk_ptr, const int32_t *blk_pts,
                      const int32_t *cand, int n_cand, const KParams &kp, double thr, int want_max, int32_t *keep,

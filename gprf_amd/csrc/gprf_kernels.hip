@@ -3416,6 +3416,22 @@ __global__ void k_done(int32_t *flag, int32_t seq) {
 
 void launch_done(int32_t *flag, int32_t seq, hipStream_t s) { hipLaunchKernelGGL(k_done, dim3(1), dim3(64), 0, s, flag, seq); }
 
+// k_sum_parts (single-process multi-device evaluation): the member contexts' partial result vectors — written by their
+// assembly kernels straight into device 0's memory (peer stores over xGMI) — added in member order (fixed: reproducible)
+// into the front context's pinned host vector.  [ll | gradX | gradC | s0 | s1]: every word is a sum.
+__global__ __launch_bounds__(256) void k_sum_parts(const double *__restrict__ slots, int n_parts, size_t stride, size_t nvec,
+                                                   double *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    double acc = slots[i];
+    for (int k = 1; k < n_parts; ++k) acc += slots[(size_t)k * stride + i];
+    out[i] = acc;
+}
+
+void launch_sum_parts(const double *slots, int n_parts, size_t stride, size_t nvec, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, slots, n_parts, stride, nvec, out);
+}
+
 void launch_assemble(const UnitTab &ut, const Pools &p, const AssembleTab &at, const KParams &kp, int n,
                      int want_gx, int want_gc, double *out, int usum_ok, const ObjTab &ob, hipStream_t s) {
     int blocks = 1 + (n + 31) / 32;

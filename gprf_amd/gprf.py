@@ -38,14 +38,16 @@ class GPRF(object):
 
     def __init__(self, X, Y, block_fn, cov, noise_var, kernelized=False, dy=None,
                  neighbor_threshold=1e-3, nonstationary=False, nonstationary_prec=False,
-                 block_idxs=None, neighbors=None, device=0, shard=None, group=None, reduce=True):
+                 block_idxs=None, neighbors=None, device=0, shard=None, group=None, reduce=True, devices=None):
         """Arguments as gprf.py:85-87.  ``kernelized`` / ``nonstationary`` are dead or broken branches in
         the reference (Appendix A.9/11) and are refused.  ``device`` = HIP device
         ordinal.  ``shard`` = (rank, world): this object evaluates only its rank's share of the units and ``llgrad``
         all-reduces the partial sums over the torch.distributed ``group`` (one process per GPU; the counterpart of
         the reference's process-pool fan-out inside llgrad, gprf.py:218-233), so every rank returns the full result
         and an optimiser can run unchanged on all ranks.  ``reduce=False`` returns the rank's partial sums instead
-        (tests, callers that reduce themselves)."""
+        (tests, callers that reduce themselves).  ``devices`` = a list of HIP device ordinals (or a count N = devices
+        0..N-1): ONE process drives them all (gprf_create_multi): the units are sharded over the devices inside the
+        library, partial sums meet on the first device — the reference's single-process driver needs no torchrun."""
         if kernelized or nonstationary or nonstationary_prec:
             raise NotImplementedError("kernelized / nonstationary GPRF variants are unreachable in the "
                                       "reference (gprf.py:90-97,302) and are not provided")
@@ -71,8 +73,12 @@ class GPRF(object):
         self.neighbor_threshold = neighbor_threshold
 
         n, dx = X.shape
+        if devices is not None:
+            if shard is not None:
+                raise ValueError("devices= (one process, several GPUs) and shard= (one process per GPU) exclude each other")
+            devices = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
         self._ctx = _capi.Context(n, dx, Y.shape[1], _capi.DIST_IDS[cov.dfn_str], _capi.KERN_IDS[cov.wfn_str],
-                                  device=device)
+                                  device=device, devices=devices)
         self._shard = (int(shard[0]), int(shard[1])) if shard is not None else (0, 1)
         self._group, self._reduce, self._dist_eval = group, bool(reduce), None
         if shard is not None:

@@ -55,6 +55,18 @@ typedef struct gprf_ctx gprf_ctx;
  * n points, dx input dims (2 or 3), dy output columns; device = HIP device ordinal. */
 int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
                 int32_t device);
+/* The same object over SEVERAL devices of one node, driven from ONE host thread — the reference's drivers are one Python
+ * process around scipy with the fan-out over units inside llgrad (gprfopt.py:377-422, gprf.py:218-233).  devices: n_devices
+ * HIP device ordinals (an ordinal may repeat: logical members on one GPU, tests).  Member k evaluates shard (k, n_devices)
+ * of the units (gprf_partition_units) on its own device and stream; X goes once into pinned host memory that every member
+ * reads; every member's assembly kernel stores its partial [ll | gradX | gradC | s0 s1] into its slot in device
+ * devices[0]'s memory (peer stores over xGMI), one kernel there adds the slots in member order into pinned host memory:
+ * one download, one synchronisation, no inter-process collective.  Every setter below applies to all members; gprf_eval /
+ * gprf_update_eval / gprf_objective evaluate over the group (the location prior is added by member 0 alone); the
+ * *_device forms, gprf_set_shard and the debug hooks are refused (GPRF_ERR_STATE); timing and table-build counters
+ * report member 0. */
+int gprf_create_multi(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
+                      int32_t n_devices, const int32_t *devices);
 int gprf_destroy(gprf_ctx *ctx);
 const char *gprf_last_error(const gprf_ctx *ctx);
 

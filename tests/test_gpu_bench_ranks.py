@@ -34,3 +34,17 @@ def test_two_rank_bench_prints_one_contract_line():
     # every compute stage's figures ride along, whichever stage is the longest in this run
     assert set(d["roofline"]["all_stages"]) <= {"potrf", "solve", "at", "grad"} and d["roofline"]["all_stages"]
     assert all(v["ms"] > 0 and v["frac"] > 0 for v in d["roofline"]["all_stages"].values())
+
+
+def test_single_process_multi_device_bench_line():
+    """bench.py --single-process --gpus 2: ONE process drives two members (both on GPU 0 here) through gprf_create_multi."""
+    env = dict(os.environ, GPRF_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--ntrain", "2000", "--nblocks", "16", "--yd", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "ONE process" in d["config"]["parallelism"]
+    assert d["roofline"]["worst"]["kernel"].startswith("k_") and 0 < d["roofline"]["worst"]["frac"] < 1
