@@ -876,6 +876,39 @@ __device__ __forceinline__ void atile_mfma_rest(const double (&a)[4], const doub
                  :
                  : "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "n"(8 * S), "n"(8 * S + 7));
 }
+// ---- hierarchical accumulation ----
+// A trailing entry used to take its 16 products per step one fused multiply-add after the other, each rounding at the
+// magnitude of the running entry: measured against an 80-bit factorisation that sequential chain is what made the device's
+// factor 1.2x as far from the truth as LAPACK's (whose blocked updates sum a block's products from zero first); a numpy
+// emulation of both orders on the north-star pair units reproduces the 1.2x and gives 0.67x for this one
+// (tests/diag/cpu_accumulation_order.py).  Now: the 16 products of a step are summed FROM ZERO in a temporary VGPR tile
+// (the same four MFMAs, srcC = 0 for the first) and enter the accumulator with ONE addition — on the vector ALU, in the
+// shadow of the next tile's MFMAs (8 accumulator reads, 4 adds, 8 writes: ~90 issue cycles against 256 of matrix pipe).
+__device__ __forceinline__ void ttile_mfma_first(d4 &t, const double (&a)[4], const double (&b)[4], int &dep) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %2, %3, 0"
+                 : "=&v"(t), "+v"(dep)
+                 : "v"(a[0]), "v"(b[0]));
+}
+__device__ __forceinline__ void ttile_mfma_rest(d4 &t, const double (&a)[4], const double (&b)[4]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %3, %4, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %5, %6, %0"
+                 : "+v"(t)
+                 : "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+}
+// tile S += t   (t must be settled: at least 18 wait states behind the MFMA that wrote it — in the chain below the next
+// tile's four MFMAs and its operand fetch lie in between)
+template <int S>
+__device__ __forceinline__ void atile_add(const d4 &t) {
+    double v[4];
+    atile_get<S>(v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += t[q];
+    atile_set<S>(v);
+}
+
 // the same on a VGPR tile (the diagonal tiles, staged through LDS): c += sum_t a[t]^T b[t]; the result is
 // settled (readable) on return
 __device__ __forceinline__ void mfma4_vgpr(d4 &c, const double (&a)[4], const double (&b)[4]) {
@@ -1120,9 +1153,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             a[k] = P[(4 * k + lg) * ldp + 16 * i + lr];
             na[k] = -a[k];
         }
-        mfma4_vgpr(t, na, a);
+        d4 sacc = {0.0, 0.0, 0.0, 0.0};      // (the step's 16 products from zero, then ONE addition: see "hierarchical accumulation")
+        mfma4_vgpr(sacc, na, a);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q];
+        for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q] + sacc[q];
     };
     auto load_tiles = [&]() {
         if constexpr (GEN && WPS == 2) {
@@ -1412,6 +1446,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                 // in straight-line code, the dead slots (below s_hi) are never visited, and one compare per tile
                 // ends the walk
                 double oa[2][4], ob[2][4];
+                d4 tt[2];      // the two temporary product tiles (slot parity)
+                tt[0] = tt[1] = d4{0.0, 0.0, 0.0, 0.0};
                 opnd_load(__builtin_amdgcn_readlane(pkv, s_end - 1), oa[0], ob[0]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { oa[1][t] = oa[0][t]; ob[1][t] = ob[0][t]; }
@@ -1432,16 +1468,27 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                                     if (S < hi2) {
                                         done = true;
                                     } else {
-                                        atile_mfma_first<S>(oa[S & 1], ob[S & 1], pkv);
+                                        ttile_mfma_first(tt[S & 1], oa[S & 1], ob[S & 1], pkv);
                                         if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
-                                        atile_mfma_rest<S>(oa[S & 1], ob[S & 1]);
+                                        ttile_mfma_rest(tt[S & 1], oa[S & 1], ob[S & 1]);
+                                        // the slot before this one in the walk (S + 1, when it was live): its products have
+                                        // settled by now — into its accumulator, behind this slot's MFMAs (issued piecewise
+                                        // BETWEEN the MFMAs it was slower: 126 vs 123 us)
+                                        if constexpr (S + 1 < SLOTS) {
+                                            if (S + 1 < end2) atile_add<S + 1>(tt[(S + 1) & 1]);
+                                        }
                                     }
                                 }
                             }
                         });
                     }
                 });
-                atile_settle();      // before anything (the next step's dump) reads the tiles
+                // the last slot of the walk (s_hi): wait for its products, then into its accumulator
+                atile_settle();
+                static_for<0, SLOTS>([&](auto sc) {
+                    constexpr int S = decltype(sc)::value;
+                    if (S == s_hi) atile_add<S>(tt[S & 1]);
+                });
             }
 #endif
         }
@@ -1829,8 +1876,12 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
                 static_for<r + 1, MAXT>([&](auto r2c) {
                     constexpr int r2 = decltype(r2c)::value;
                     if (r2 < T) {
+                        // (the step's 16 products from zero, then ONE addition into the running tile: "hierarchical
+                        // accumulation" above k_potrf_reg — the running tile otherwise rounds 16 times per step at its own magnitude)
+                        d4 t16 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[r2] = mfma(-pr[(4 * s) * LDP + 16 * (r2 - r - 1)], w[s], acc[r2]);
+                        for (int s = 0; s < 4; ++s) t16 = mfma(-pr[(4 * s) * LDP + 16 * (r2 - r - 1)], w[s], t16);
+                        acc[r2] += t16;
                     }
                 });
                 GPRF_SST(4)

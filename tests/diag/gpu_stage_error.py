@@ -21,7 +21,9 @@ ctx.debug_run(X, 6)
 nb = g.n_blocks
 rng = np.random.RandomState(3)
 rows = []
-for q in rng.choice(len(g.neighbors), 4, replace=False):
+stage_rows = []
+keep = []
+for q in rng.choice(len(g.neighbors), int(os.environ.get("NUNITS", "4")), replace=False):
     i, j = g.neighbors[q]
     idx = np.concatenate([g.block_idxs[i], g.block_idxs[j]])
     m = len(idx)
@@ -63,11 +65,44 @@ for q in rng.choice(len(g.neighbors), 4, replace=False):
     gt = np.asarray(gt, dtype=np.float64)
     gdev = ctx.debug_fetch(nb + q, 4)[:m, :2]
     e = lambda a: float(np.max(np.abs(a - gt)))
-    print("     gradient rows |x - true| max:  device %.2e   numpy from the device's W, A %.2e   numpy from LAPACK's W, A %.2e   (max|g| %.2e)"
-          % (e(gdev), e(grad_np(Wd, Ad)), e(grad_np(W64, A64)), np.abs(gt).max()))
+    # which stage carries the excess: LAPACK's triangular solves applied to the DEVICE's factor, and the device's K
+    mp_ = (m + 15) // 16 * 16
+    Ud_full = np.triu(ctx.debug_fetch(nb + q, 0)[:m, :m])
+    W_dU = sl.solve_triangular(Ud_full, np.eye(m), trans='T', lower=False)
+    A_dU = sl.cho_solve((Ud_full, False), Yu)
+    print("     gradient rows |x - true| max:  device %.2e   numpy from the device's W, A %.2e   numpy from LAPACK's W, A %.2e   "
+          "LAPACK solves on the DEVICE's U %.2e   (max|g| %.2e)"
+          % (e(gdev), e(grad_np(Wd, Ad)), e(grad_np(W64, A64)), e(grad_np(W_dU, A_dU)), np.abs(gt).max()))
+    keep.append((q, idx, gt, d64))
+    stage_rows.append((e(gdev), e(grad_np(Wd, Ad)), e(grad_np(W64, A64)), e(grad_np(W_dU, A_dU))))
     rows.append((m, f(Ud, Ut), f(U64, Ut), f(Wd, Wt), f(W64, Wt), f(Ad, At), f(A64, At)))
     print("unit %4d m=%3d  U: gpu %.2e lapack %.2e | W: gpu %.2e lapack %.2e | A = K^-1 Y: gpu %.2e lapack %.2e   (max-abs / max|true|)"
           % ((q,) + rows[-1]))
 r = np.array(rows)
 print("means: U gpu/lapack %.2f   W %.2f   A %.2f" % (r[:, 1].mean() / r[:, 2].mean(), r[:, 3].mean() / r[:, 4].mean(), r[:, 5].mean() / r[:, 6].mean()))
+# ... and LAPACK on the DEVICE's kernel matrix (fill-only run: the K pool holds the 64 x 64 blocks ti <= tj)
+ctx.debug_run(X, 0)
+kerr = []
+for (q, idx, gt, d64) in keep:
+    m = len(idx)
+    Kd = ctx.debug_fetch(nb + q, 0)[:m, :m]
+    Kd = np.triu(Kd) + np.triu(Kd, 1).T
+    Xu, Yu = X[idx], sd.SY[idx]
+    U_k = sl.cholesky(Kd, lower=False)
+    W_k = sl.solve_triangular(U_k, np.eye(m), trans='T', lower=False)
+    A_k = sl.cho_solve((U_k, False), Yu)
+    M = A_k @ A_k.T - 50.0 * (W_k.T @ W_k)
+    Kz = np.exp(-np.sum(d64 * d64, axis=2)); np.fill_diagonal(Kz, 0.0)
+    out = np.zeros((m, 2))
+    for dd in range(2):
+        D = -2.0 * (Xu[:, None, dd] - Xu[None, :, dd]) / 0.06 ** 2 * Kz
+        out[:, dd] = np.sum(M * D, axis=1)
+    K64 = np.exp(-np.sum(d64 * d64, axis=2)) + 0.01 * np.eye(m)
+    kerr.append((float(np.max(np.abs(out - gt))), float(np.max(np.abs(Kd - K64))), float(np.max(np.abs(Kd - K64) / K64))))
+kerr = np.array(kerr)
+print("LAPACK everything on the DEVICE's K: gradient-row error mean %.3e   (max |K_dev - K_numpy| %.2e abs, %.2e relative)"
+      % (kerr[:, 0].mean(), kerr[:, 1].max(), kerr[:, 2].max()))
+sr = np.array(stage_rows)
+print("gradient-row error means over %d units: device %.3e | numpy(device W, A) %.3e | numpy(LAPACK W, A) %.3e | LAPACK solves on device U %.3e"
+      % ((len(sr),) + tuple(sr.mean(axis=0))))
 g.close()

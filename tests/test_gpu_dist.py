@@ -139,7 +139,9 @@ def test_two_rank_optimisation_and_jitter_in_lockstep():
     one = [t[2] for t in obj.trace]
     g.close()
     assert len(one) == len(a["trace"])
-    assert np.allclose(one, a["trace"], rtol=1e-12, atol=0)
+    # (the objective passes through zero along the run: rounding-level differences between the two summation orders are
+    # measured against the largest value of the trace, not against the value next to the sign change)
+    assert np.allclose(one, a["trace"], rtol=1e-12, atol=1e-12 * np.max(np.abs(one)))
     assert np.allclose(rx, a["x"], rtol=0, atol=1e-9)
     # --- the not-PD unit: same answer on both ranks, equal to the single-process answer
     from gprf_amd import GPCov

@@ -92,7 +92,7 @@ def test_gradient_against_oracle_and_extended_precision(sdata, local_dist):
     print("local_dist=%g max|gX|=%.4g | gpu-oracle %.3g | gpu-true %.3g | oracle-true %.3g | ll rel: gpu-oracle %.2g gpu-true %.2g oracle-true %.2g"
           % (local_dist, gmax, e_go, e_gt, e_ot, abs(ll - o_ll) / abs(o_ll), abs(float(ll - t_ll)) / abs(float(t_ll)),
              abs(float(o_ll - t_ll)) / abs(float(t_ll))))
-    assert e_gt <= 1.5 * e_ot                      # (a) as accurate as the reference CPU path
+    assert e_gt <= 1.1 * e_ot                      # (a) as accurate as the reference CPU path (measured r03: 0.98x / 0.74x)
     # (b) agreement at the common rounding floor: at most TWICE what round 1 measured on MI355X (1.94e-8 without /
     # 1.52e-7 with the 342 pair units: profiles/r01_final_pytest_gpu.log) — a 2x regression fails
     assert e_go <= (4e-8 if local_dist == 1.0 else 3e-7)
@@ -145,15 +145,14 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
     """Per unit, not only on the assembled gradient: for pair units of the north-star configuration (the largest, the
     smallest and a seeded sample) the device's gradient rows are compared with the 80-bit evaluation next to the oracle's
     (fp64 LAPACK) rows.  Both are rounding noise of the same order whose per-unit maxima scatter by a factor of two either
-    way.  Measured on MI355X (12 units, m 149..250): |gpu - true| max 3.0e-8, mean 2.3e-8; |oracle - true| max 2.1e-8, mean
-    1.6e-8; ratio mean 1.50, 0.77 .. 2.38 — unit by unit the device's rows are about 1.5x as far from the truth as
-    LAPACK's.  Where it enters (tests/diag/gpu_stage_error.py, tests/diag/cpu_tile_inverse_emulation.py): the device's U and
-    W = U^-T are 1.1-1.2x LAPACK's distance from the 80-bit factors; numpy fp64 fed with the DEVICE's W and A reproduces the
-    device's rows (the MFMA product, the kernel re-evaluation and the reductions add nothing), fed with LAPACK's it reproduces
-    the oracle's; the explicit 16 x 16 tile inverses of the substitution are not it (an emulation with them is within 4 % of
-    LAPACK) — it is the factorisation: reciprocal multiplies in the pivot rows, MFMA accumulation order.  On the ASSEMBLED
-    gradient the device is as close or closer (test above).  Asserted with headroom for the scatter: pooled maximum and mean ratio at
-    most 2, no single unit more than 3.5x further from the truth than the oracle is."""
+    way.  Round 2 measured the device 1.5x as far from the truth as LAPACK unit by unit; the cause was the order of
+    accumulation in the factorisation (every product of a trailing update rounding at the running entry's magnitude:
+    tests/diag/gpu_stage_error.py located it in U, tests/diag/cpu_accumulation_order.py reproduces the 1.2x of the factor in
+    numpy and the cure): since round 3 a step's 16 products are summed from zero and enter the running tile with one
+    addition, in the Cholesky and in the triangular solve.  Measured on MI355X (12 units, m 149..250): |gpu - true| max
+    2.3e-8, mean 1.31e-8; |oracle - true| max 2.09e-8, mean 1.58e-8; ratio mean 0.88, 0.49 .. 1.67
+    (profiles/r03_numerics.log).  Asserted: pooled maximum at most 1.25x the oracle's, mean ratio at most 1.1, no single unit
+    more than 2x further from the truth than the oracle is."""
     from ld_truth import unit_llgrad_ld
     g = sdata.build_gprf(local_dist=0.1)
     g.llgrad(grad_X=True)
@@ -180,7 +179,7 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
     print("pair units vs 80-bit: %d units (m %d..%d)  |gpu-true| max %.3g mean %.3g   |oracle-true| max %.3g mean %.3g   "
           "ratio mean %.2f min %.2f max %.2f" % (len(pick), sizes[pick].min(), sizes[pick].max(), e_gpu.max(), e_gpu.mean(),
                                                  e_orc.max(), e_orc.mean(), ratio.mean(), ratio.min(), ratio.max()))
-    assert e_gpu.max() <= 2.0 * e_orc.max()
-    assert ratio.mean() <= 2.0
-    assert ratio.max() <= 3.5
+    assert e_gpu.max() <= 1.25 * e_orc.max()
+    assert ratio.mean() <= 1.1
+    assert ratio.max() <= 2.0
     g.close()

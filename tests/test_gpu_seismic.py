@@ -103,7 +103,10 @@ def test_device_tree_routing_equals_host_routing():
         assert all(np.array_equal(a, b) for a, b in zip(g.block_idxs, host)), k
         slow.update_X(X2)
         a, b = g.llgrad(grad_X=True, grad_cov=True), slow.llgrad(grad_X=True, grad_cov=True)
-        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # (reading block_idxs above installed the device's partition as it is: its launch-wide tile bound follows a shrinking
+        # partition with hysteresis, the host-partition object's is exact — another kernel instantiation can change the last bit)
+        assert np.isclose(a[0], b[0], rtol=1e-13, atol=0)
+        assert np.allclose(a[1], b[1], rtol=0, atol=1e-13 * np.abs(b[1]).max()) and np.allclose(a[2], b[2], rtol=1e-12)
     assert g._centers_of is reblock.tree                     # the device path was the one taken
     assert any(len(b) == 0 for b in g.block_idxs)
     # unchanged points: no partition comes back
