@@ -389,10 +389,12 @@ def main():
         # (traffic: only when the committed profile was taken on exactly these native sources — otherwise null and why)
         try:
             tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
-            key = {"potrf": "k_potrf_dual", "solve": "k_solve_panel", "at": "k_at", "grad": "k_mgrad", "fill": "k_fill"}[dom]
+            # (the Cholesky stage is two kernels side by side: their traffic adds up)
+            keys = {"potrf": ("k_potrf_reg_gen", "k_potrf_reg2_gen"), "solve": ("k_solve_panel",), "at": ("k_at",),
+                    "grad": ("k_mgrad", "k_gx_finalize"), "fill": ("k_fill",)}[dom]
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 if tr.get("source_hash") == source_hash():
-                    roof["traffic"] = tr[key]["bytes_per_launch"]
+                    roof["traffic"] = sum(tr[k_]["bytes_per_launch"] for k_ in keys)
                     roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these sources, hash %s)" % (
                         TRAFFIC_FILE, tr.get("source_hash"))
                 else:

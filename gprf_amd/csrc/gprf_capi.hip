@@ -165,6 +165,10 @@ struct gprf_ctx {
     hipStream_t red_stream = nullptr;
     std::vector<hipEvent_t> ev_kid;
 
+    // host-side phases of the host-in / host-out evaluation (GPRF_HOST_TRACE=1: printed when the context is destroyed)
+    double host_us[4] = {0, 0, 0, 0};     // copy X in | enqueue | wait | copy result out
+    uint64_t host_n = 0;
+
     // timing: a ring of event sets so that evaluations can be timed back to back without a host sync;
     // a slot's elapsed times are folded into the running totals when the slot is about to be reused
     static constexpr int RING = 32;
@@ -904,7 +908,9 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
     size_t nout = 1 + nx + c->ncov + 2;
     // zero-copy: the kernels read X from, and write the result to, pinned host memory directly (160 KB each way at
     // n = 10000: two fabric round trips instead of three copy commands with their launch latencies)
+    auto tp0 = std::chrono::steady_clock::now();
     memcpy(c->h_X.p, X, nx * sizeof(double));
+    auto tp1 = std::chrono::steady_clock::now();
     (void)nout;
     int any_reblocked = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -912,8 +918,14 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
         int rc = enqueue_eval(c, c->h_X.d, want_gx, want_gc, c->h_out.d, s, 6, reblock, true);
         c->objective_call = false;
         if (rc != GPRF_OK) return rc;
+        auto tp2 = std::chrono::steady_clock::now();
         int32_t rb = 0;
         rc = finish_eval(c, s, first_bad_unit, &rb);
+        auto tp3 = std::chrono::steady_clock::now();
+        c->host_us[0] += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+        c->host_us[1] += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
+        c->host_us[2] += std::chrono::duration<double, std::micro>(tp3 - tp2).count();
+        tp0 = tp1 = tp3;
         any_reblocked |= rb;
         if (rc == GPRF_RETRY) { reblock = false; continue; }      // the new partition is in d_assign; tables: need_build
         if (reblocked) *reblocked = any_reblocked;
@@ -921,6 +933,8 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
         *ll_out = c->h_out.p[0];
         if (want_gx) memcpy(gradX_out, c->h_out.p + 1, nx * sizeof(double));
         if (want_gc) memcpy(gradC_out, c->h_out.p + 1 + nx, c->ncov * sizeof(double));
+        c->host_us[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp3).count();
+        c->host_n++;
         return GPRF_OK;
     }
     return fail(c, GPRF_ERR_STATE, "the unit tables did not fit the workspace after growing it twice");
@@ -1031,6 +1045,10 @@ int gprf_create_multi(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t
 
 int gprf_destroy(gprf_ctx *c) {
     if (!c) return GPRF_OK;
+    if (c->host_n > 0 && getenv("GPRF_HOST_TRACE"))
+        fprintf(stderr, "gprf host phases over %llu evaluations (us): copy X in %.1f | enqueue %.1f | wait %.1f | copy result out %.1f\n",
+                (unsigned long long)c->host_n, c->host_us[0] / c->host_n, c->host_us[1] / c->host_n, c->host_us[2] / c->host_n,
+                c->host_us[3] / c->host_n);
     for (gprf_ctx *k : c->kids) (void)gprf_destroy(k);
     c->kids.clear();
     (void)hipSetDevice(c->device);
