@@ -1004,7 +1004,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // every LDS row offset below is an instruction immediate
     // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
     // solved panel then goes to global memory inside its own step (copy_now below), never from the other buffer
-    constexpr int ldp = WPS == 1 ? POTRF_REG_LDP : POTRF_REG2_LDP;
+    constexpr bool WHOLE_CU = WPS == 1 || RW == 8;     // one workgroup per CU: the wide pitch (units of up to 16 tiles)
+    constexpr int ldp = WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP;
     constexpr int NPB = WPS == 1 ? 2 : 1;
     double *P0 = lds;                     // [NPB][16][ldp] row panel j of U in buffer j & (NPB - 1): a pure-factor wave 0
     double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
@@ -1026,24 +1027,31 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // taking idx % 4 == 3), the rest to the workers as before.  Wave 0's tiles then lie in the first rows: they are
     // the first to retire, so its trailing work (which runs after its factor, on the critical path) is over after
     // a few steps instead of staying a quarter of everything.
-    static_assert(RW == 4, "three workers + the factor wave");
+    // (RW waves: NW = RW - 1 workers + the factor wave; the text above is RW = 4.  RW = 8 — eight waves of 256 registers,
+    // ONE workgroup per CU, seven workers x 20 slots for every unit of up to 16 tiles, one kernel and one launch — was built
+    // and measured in round 3: a unit finishes 20 % sooner (T = 15: 89 vs 104-113 us, T = 13: 71 vs 97) but holds a whole CU,
+    // and CU-time is what the stage is short of: 140 us against 123 with the two instantiations)
+    static_assert(RW == 4 || RW == 8, "RW - 1 workers + the factor wave");
+    constexpr int NW = RW - 1;
     const int total = T * (T - 1) / 2;
-    const int ov = total > 3 * SLOTS ? total - 3 * SLOTS : 0;
-    const int head = 4 * ov < total ? 4 * ov : total;
+    const int ov = total > NW * SLOTS ? total - NW * SLOTS : 0;      // (a larger share for wave 0 — total / 6 .. / 14 — measured: no change)
+    const int head = RW * ov < total ? RW * ov : total;
     const bool w0busy = ov > 0;                        // wave 0 owns tiles too
     const bool mine = wave > 0 || w0busy;
-    const bool copy_now = w0busy || WPS == 2;          // the tile-owning waves store a solved panel in its own step
-    const int wpos = wave == 0 ? 3 : wave - 1;         // position in the four-way deal; workers: also in the three-way
-    const int nhead = (head - wpos + 3) >> 2;          // this wave's tiles of the four-way part (head >= 3 or 0)
+    // the tile-owning waves store a solved panel in its own step, a share each (always with one panel buffer; with two, a
+    // wave 0 without tiles does it alone from the other buffer during the next substitution)
+    const bool copy_now = w0busy || NPB == 1;
+    const int wpos = wave == 0 ? NW : wave - 1;        // position in the RW-way deal; workers: also in the NW-way
+    const int nhead = head - wpos + NW < 0 ? 0 : (head - wpos + NW) / RW;      // this wave's tiles of the RW-way part
     // tiles of this wave among idx < r
     auto cnt = [&](int r) {
         if (r <= head) {
-            int c = (r - wpos + 3) >> 2;
-            return c < 0 ? 0 : c;
+            int c = r - wpos + NW;
+            return c < 0 ? 0 : c / RW;
         }
         if (wave == 0) return nhead;
-        int c = (r - head - wpos + 2) / 3;
-        return nhead + (r - head - wpos + 2 < 0 ? 0 : c);
+        int c = r - head - wpos + NW - 1;
+        return nhead + (c < 0 ? 0 : c / NW);
     };
     // lane s: slot s -> tile, 32 * tile row + tile column, or -1 (fetched with v_readlane / a shuffle where
     // needed: 30-odd live SGPRs would crowd out the row pointers);  lane j: s_hi of step j = this wave's tiles
@@ -1051,7 +1059,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     int pkv = -1, shv = 0;
     {
         int sl = lane;
-        int idx = sl < nhead ? 4 * sl + wpos : (wave == 0 ? total : head + 3 * (sl - nhead) + wpos);
+        int idx = sl < nhead ? RW * sl + wpos : (wave == 0 ? total : head + NW * (sl - nhead) + wpos);
         int i = 0, rs = 0, rl = T - 1;
         while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
         if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
@@ -1423,9 +1431,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution ...
             else if (copy_now) copy_panel(j, wave - 1, RW - 1);      // ... or, single-buffered, the three workers now)
             GPRF_STAMP3(0)
-            // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % 3
+            // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % NW
             if (wave > 0)
-                for (int i = j + 2 + (wave - 1 + 3 * T - (j + 2)) % 3; i < T; i += 3) diag_update(i);
+                for (int i = j + 2 + (wave - 1 + NW * T - (j + 2)) % NW; i < T; i += NW) diag_update(i);
 #endif
             GPRF_STAMP3(1)
             // live tiles: slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS panel
@@ -2723,7 +2731,7 @@ void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, d
 // dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
 // granted for (kernel slot, current device)
 static bool lds_needs_optin(int kernel_slot, size_t lds) {
-    static size_t granted[4][64] = {};
+    static size_t granted[6][64] = {};
     if (lds <= 48 * 1024) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
