@@ -617,12 +617,14 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[slot][stage], s); ++stage; };
     mark();      // stage "gather" = re-partition + table build (when asked for) + the coordinate gather
     int from_chunks = 0, force = c->need_build ? 1 : 0;
+    bool fused_build = false;      // table build + coordinate scatter as one launch (k_build_scatter)
     if (reblock) {
         rc = enqueue_partition(c, d_X, s);
         if (rc != GPRF_OK) return rc;
         if (d_X != c->d_X.p) d_X = c->d_X.p;      // the partition kernel's copy
         from_chunks = 1;
-        launch_build_tables(make_build(c), 1, force, c->epoch, s);
+        fused_build = build_scatter_fits(make_build(c));
+        if (!fused_build) launch_build_tables(make_build(c), 1, force, c->epoch, s);
     } else if (c->need_build) {
         launch_build_tables(make_build(c), 0, 1, c->epoch, s);
     }
@@ -637,7 +639,8 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
                    c->d_pe.p, c->d_ebase.p, c->d_ewgt.p,
                    c->d_res.p, host_io ? c->h_res.d : nullptr, (int)c->res_words};
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
-    launch_scatter_x(make_build(c), d_X, c->dx, c->dist_id, from_chunks, force, c->epoch, s);
+    if (fused_build) launch_build_scatter(make_build(c), d_X, c->dx, c->dist_id, force, c->epoch, s);
+    else launch_scatter_x(make_build(c), d_X, c->dx, c->dist_id, from_chunks, force, c->epoch, s);
     mark();
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
@@ -672,12 +675,12 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         ob.var = c->obs_std * c->obs_std;
         ob.part = c->d_xpart.p;
     }
-    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, ob, s);
-    mark();
     // control words, unit status, block sizes -> pinned host: one download (or the assembly kernel's mirror)
     c->poll_pending = false;
     const bool poll = host_io && stop_after >= 5 && c->spin && c->h_done.p;
     if (poll) c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, ob, s);
+    mark();
     if (objective) {
         const double nel = (double)c->n * c->dx;
         const double xp_const = -0.5 * nel * std::log(2.0 * M_PI * (c->obs_std * c->obs_std));
@@ -1324,8 +1327,12 @@ int gprf_assign_blocks(gprf_ctx *c, const double *X, int32_t *changed, int32_t *
         HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
         rc = enqueue_partition(c, c->d_X.p, s);
         if (rc != GPRF_OK) return rc;
-        launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, c->epoch, s);
-        launch_scatter_x(make_build(c), c->d_X.p, c->dx, c->dist_id, 1, c->need_build ? 1 : 0, c->epoch, s);
+        if (build_scatter_fits(make_build(c))) {
+            launch_build_scatter(make_build(c), c->d_X.p, c->dx, c->dist_id, c->need_build ? 1 : 0, c->epoch, s);
+        } else {
+            launch_build_tables(make_build(c), 1, c->need_build ? 1 : 0, c->epoch, s);
+            launch_scatter_x(make_build(c), c->d_X.p, c->dx, c->dist_id, 1, c->need_build ? 1 : 0, c->epoch, s);
+        }
         c->need_build = false;
         c->pending_epoch = c->epoch;
         HIP_TRY(c, hipGetLastError());

@@ -171,6 +171,10 @@ void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epo
 // every evaluation: coordinates into the unit rows (+ positions and unit row -> point when rebuilding)
 void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, int from_chunks, int force, int epoch,
                       hipStream_t s);
+// both of the above as one launch, for a partition made by launch_assign / launch_route in this evaluation
+// (build_scatter_fits: small enough for every workgroup to redo the scans in LDS)
+bool build_scatter_fits(const BuildTab &bt);
+void launch_build_scatter(const BuildTab &bt, const double *X, int dx, int dist_id, int force, int epoch, hipStream_t s);
 // skip_T: units of at most that many tiles per edge are not filled (0 = all)
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int skip_T, hipStream_t s);
 // whether the register-resident Cholesky generates the kernel matrices of its units (at most potrf_gen_maxT() tiles per

@@ -2941,45 +2941,24 @@ __device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long
     *tb = sb;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_chunks, int force, int epoch) {
-    __shared__ long long sh[8];
-    __shared__ int s_maxm;
-    if (!rebuilding(bt, force, epoch)) return;
-    int t = threadIdx.x, lane = t & 63;
-    if (from_chunks) {
-        int b = blockIdx.x * 4 + (t >> 6);
-        if (b < bt.n_blocks) {
-            int run = 0;
-            for (int c0 = 0; c0 < bt.n_chunks; c0 += 64) {
-                int c = c0 + lane;
-                int *e = bt.cnt + (size_t)c * bt.n_blocks + b;
-                int v = c < bt.n_chunks ? *e : 0;
-                int inc = v;
-                for (int off = 1; off < 64; off <<= 1) {
-                    int u = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += u;
-                }
-                if (c < bt.n_chunks) *e = run + inc - v;
-                run += __shfl(inc, 63, 64);
-            }
-            if (lane == 0) bt.bsize[b] = run;
-        }
-        return;
-    }
-    // (the unit sizes stay in LDS for the second pass: every global round trip of this one-workgroup kernel is exposed)
-    constexpr int M_LDS = 8192;
-    __shared__ int s_m[M_LDS], s_ro[M_LDS];
-    __shared__ unsigned s_mo[M_LDS];
-    if (t == 0) s_maxm = 0;
+// the unit scan of one workgroup of SCAN_THREADS threads (k_build's second launch; the table workgroup of k_build_scatter):
+// bsz = the block sizes (global or LDS), s_m / s_ro / s_mo = LDS scratch of M_LDS words each
+// pre (may be nullptr): unit_bi / unit_bj / ids of units t and t + 256, loaded by the caller ahead of time
+template <int M_LDS>
+__device__ __forceinline__ void unit_tables(const BuildTab &bt, const int *bsz, int *s_m, int *s_ro, unsigned *s_mo,
+                                            long long *sh /* LDS [8] */, int *s_maxm_p /* LDS */, const int (*pre)[2] = nullptr) {
+    int t = threadIdx.x;
+    if (t == 0) *s_maxm_p = 0;
     __syncthreads();
     long long rows = 0, mat = 0;
     for (int l0 = 0; l0 < bt.n_local; l0 += SCAN_THREADS) {
         int l = l0 + t;
         int m = 0, mi = 0;
         if (l < bt.n_local) {
-            mi = bt.bsize[bt.unit_bi[l]];
-            int bj = bt.unit_bj[l];
-            m = mi + (bj >= 0 ? bt.bsize[bj] : 0);
+            int bi = (pre && l0 < 512) ? pre[0][l0 >> 8] : bt.unit_bi[l];
+            int bj = (pre && l0 < 512) ? pre[1][l0 >> 8] : bt.unit_bj[l];
+            mi = bsz[bi];
+            m = mi + (bj >= 0 ? bsz[bj] : 0);
         }
         long long mp = (m + 15) & ~15;
         long long a = mp, b = mp * mp, ta, tb;
@@ -2991,13 +2970,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
             bt.row_off[l] = (int32_t)r0;
             bt.mat_off[l] = mat + b;
             if (l < M_LDS) { s_m[l] = m; s_ro[l] = (int32_t)r0; s_mo[l] = (unsigned)((mat + b) >> 8); }
-            atomicMax(&s_maxm, m);
+            atomicMax(s_maxm_p, m);
         }
         rows += ta;
         mat += tb;
     }
     __syncthreads();
-    int maxm = s_maxm;
+    int maxm = *s_maxm_p;
     int maxT = ((maxm + 15) & ~15) >> 4;
     bool over = rows > bt.cap_rows || mat > bt.cap_mat || maxT > bt.maxT_bound || maxm > MAX_MP;
     // the launch-slot records (SlotRec) in launch order, and the Cholesky's two launch lists (units of more than
@@ -3009,7 +2988,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
         SlotRec r = {0, 0, 0, 0u};
         long long big = 0, one = 0, tb_, to_;
         if (k < bt.n_local) {
-            int u = bt.ids[k];
+            int u = (pre && k0 < 512) ? pre[2][k0 >> 8] : bt.ids[k];
             r.u = u;
             r.m = over ? 0 : (u < M_LDS ? s_m[u] : bt.m[u]);
             r.row_off = u < M_LDS ? s_ro[u] : bt.row_off[u];
@@ -3053,6 +3032,75 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
     }
 }
 
+__global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_chunks, int force, int epoch) {
+    __shared__ long long sh[8];
+    __shared__ int s_maxm;
+    if (!rebuilding(bt, force, epoch)) return;
+    int t = threadIdx.x, lane = t & 63;
+    if (from_chunks) {
+        int b = blockIdx.x * 4 + (t >> 6);
+        if (b < bt.n_blocks) {
+            int run = 0;
+            for (int c0 = 0; c0 < bt.n_chunks; c0 += 64) {
+                int c = c0 + lane;
+                int *e = bt.cnt + (size_t)c * bt.n_blocks + b;
+                int v = c < bt.n_chunks ? *e : 0;
+                int inc = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    int u = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += u;
+                }
+                if (c < bt.n_chunks) *e = run + inc - v;
+                run += __shfl(inc, 63, 64);
+            }
+            if (lane == 0) bt.bsize[b] = run;
+        }
+        return;
+    }
+    // (the unit sizes stay in LDS for the second pass: every global round trip of this one-workgroup kernel is exposed)
+    constexpr int M_LDS = 8192;
+    __shared__ int s_m[M_LDS], s_ro[M_LDS];
+    __shared__ unsigned s_mo[M_LDS];
+    unit_tables<M_LDS>(bt, bt.bsize, s_m, s_ro, s_mo, sh, &s_maxm);
+}
+
+// one point's coordinate record into its row of every local unit that contains its block b (position pos inside the
+// block); row_of(unit, side) = the first row of that block inside the unit
+template <class RowOf>
+__device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double *__restrict__ X, int dx, int geo, int p,
+                                             int e_first, int e_end, int pos, bool rebuild, RowOf row_of) {
+    double r0, r1, r2, r3, r4 = 0.0;
+    if (geo) {
+        // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
+        double lon = X[(size_t)p * dx], lat = X[(size_t)p * dx + 1], z = X[(size_t)p * dx + 2];
+        double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
+        r0 = sin(hl); r1 = cos(hl); r2 = sin(hn); r3 = cos(hn); r4 = z;      // GEO_SLH, GEO_CLH, GEO_SNH, GEO_CNH, GEO_Z
+    } else {
+        r0 = X[(size_t)p * dx];
+        r1 = dx > 1 ? X[(size_t)p * dx + 1] : 0.0;
+        r2 = dx > 2 ? X[(size_t)p * dx + 2] : 0.0;
+        r3 = 0.0;
+    }
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    if (rebuild) { bt.pe[2 * p] = e_first; bt.pe[2 * p + 1] = e_end - e_first; }      // k_assemble's shortcuts
+    for (int e = e_first; e < e_end; ++e) {
+        int ent = bt.bu_ent[e];
+        int u = ent >> 1;
+        int row = row_of(u, ent & 1) + pos;
+        if (rebuild) {
+            bt.upt[row] = p;
+            if (pos == 0) bt.ebase[e] = row;      // the block's first row inside this unit (one writer per entry)
+        }
+        d2v *dst = reinterpret_cast<d2v *>(bt.Xu + (size_t)row * (geo ? GEO_STRIDE : XPAD));      // 32- / 64-byte rows
+        dst[0] = d2v{r0, r1};
+        dst[1] = d2v{r2, r3};
+        if (geo) {
+            dst[2] = d2v{r4, 0.0};
+            dst[3] = d2v{0.0, 0.0};
+        }
+    }
+}
+
 // k_scatter_x (every evaluation): a point's coordinate record into its row of every local unit that contains its
 // block — position posb of the block, rows of block j after block i's (gprf.py:322-326) — and, when the tables are
 // being rebuilt, the position itself (from the chunk ranks) and the unit row -> point table.
@@ -3089,37 +3137,155 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
         pos = bt.posb[p];
     }
     if (bt.ctl[CTL_OVERFLOW]) return;
-    double r0, r1, r2, r3, r4 = 0.0;
-    if (geo) {
-        // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
-        double lon = X[(size_t)p * dx], lat = X[(size_t)p * dx + 1], z = X[(size_t)p * dx + 2];
-        double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
-        r0 = sin(hl); r1 = cos(hl); r2 = sin(hn); r3 = cos(hn); r4 = z;      // GEO_SLH, GEO_CLH, GEO_SNH, GEO_CNH, GEO_Z
+    scatter_rows(bt, X, dx, geo, p, bt.bu_ptr[b], bt.bu_ptr[b + 1], pos, rebuild,
+                 [&](int u, int side) { return bt.row_off[u] + (side ? bt.off_j[u] : 0); });
+}
+
+// k_build_scatter: k_build (both launches) and k_scatter_x as ONE launch for a partition that came from k_assign / k_route
+// in this evaluation.  Three dependent launches of tiny kernels cost 28 us of a 430 us evaluation, nearly all of it launch
+// ramps, drains and exposed memory round trips; an arrival ticket between them was no better (a grid-wide wait is a launch
+// boundary by another name).  Here nobody waits for anybody: EVERY workgroup derives what it needs by itself, in LDS — a
+// histogram of the whole block assignment (n words, read once as int4: the block sizes, and how many points of each block
+// come before the workgroup's own 256), then the unit scan (sizes, row offsets) — and scatters its 256 points; one more
+// workgroup (the last) only writes the tables (unit_tables).  The redundant work is a few thousand integer operations per
+// workgroup.  Limits (else the three-launch path): FB_MAX_BLOCKS blocks, FB_MAX_UNITS local units, FB_MAX_POINTS points.
+constexpr int FB_MAX_BLOCKS = 1024, FB_MAX_UNITS = 2048, FB_MAX_POINTS = 1 << 15;
+__global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double *__restrict__ X, int dx, int geo, int force,
+                                                       int epoch) {
+    static_assert(SCAN_THREADS == 256 && CHUNK == 64, "four chunks per workgroup");
+    __shared__ long long sh[8];
+    __shared__ int s_maxm;
+    __shared__ int s_lo[FB_MAX_BLOCKS], s_bsize[FB_MAX_BLOCKS], s_pref[4][FB_MAX_BLOCKS];
+    __shared__ int s_m[FB_MAX_UNITS], s_ro[FB_MAX_UNITS];
+    __shared__ unsigned s_x[FB_MAX_UNITS];      // table workgroup: mat_off >> 8; the others: off_j
+    const bool rebuild = rebuilding(bt, force, epoch);
+    const int npw = (bt.n + 255) / 256;         // point workgroups; workgroup npw writes the tables
+    const int t = threadIdx.x;
+    const bool table_wg = (int)blockIdx.x == npw;
+    if (table_wg && !rebuild) return;
+    // the point's own words first (their round trips run under the scans below)
+    const int p = blockIdx.x * 256 + t;
+    const int b = p < bt.n ? bt.assign[p] : -1;
+    const int my_rank = p < bt.n ? (rebuild ? bt.rank[p] : bt.posb[p]) : 0;
+    const int e_first = b >= 0 ? bt.bu_ptr[b] : 0, e_end = b >= 0 ? bt.bu_ptr[b + 1] : 0;
+    bool over = false;
+    if (rebuild) {
+        const int nb = bt.n_blocks, p0 = 256 * (int)blockIdx.x, n = bt.n;
+        // (every global round trip of this kernel is exposed: what the unit scan needs is asked for now)
+        int pre[3][2] = {{0, 0}, {-1, -1}, {0, 0}};      // unit_bi, unit_bj, ids (the last for the table workgroup)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (t + 256 * q < bt.n_local) {
+                pre[0][q] = bt.unit_bi[t + 256 * q];
+                pre[1][q] = bt.unit_bj[t + 256 * q];
+                if (table_wg) pre[2][q] = bt.ids[t + 256 * q];
+            }
+        for (int k = t; k < nb; k += 256) {
+            s_lo[k] = 0; s_bsize[k] = 0;        // (s_bsize: the points from p0 on, until the two are added)
+            s_pref[0][k] = 0; s_pref[1][k] = 0; s_pref[2][k] = 0; s_pref[3][k] = 0;
+        }
+        __syncthreads();
+        {
+            const int4 *a4 = reinterpret_cast<const int4 *>(bt.assign);
+            const int n4 = n >> 2;
+            for (int i0 = t; i0 < n4; i0 += 8 * 256) {      // eight loads in flight per thread
+                int4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = i0 + 256 * q < n4 ? a4[i0 + 256 * q] : int4{-1, -1, -1, -1};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = 4 * (i0 + 256 * q);
+                    const int bb[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bb[k] >= 0) atomicAdd(idx + k < p0 ? &s_lo[bb[k]] : &s_bsize[bb[k]], 1);
+                }
+            }
+            if (4 * n4 + t < n) {
+                int bb = bt.assign[4 * n4 + t];
+                if (bb >= 0) atomicAdd(4 * n4 + t < p0 ? &s_lo[bb] : &s_bsize[bb], 1);
+            }
+            if (!table_wg && b >= 0) atomicAdd(&s_pref[t >> 6][b], 1);      // the workgroup's own four chunks
+        }
+        __syncthreads();
+        for (int k = t; k < nb; k += 256) {
+            // s_pref[j] = points of block k before chunk j of this workgroup
+            int lo = s_lo[k], o0 = s_pref[0][k], o1 = s_pref[1][k], o2 = s_pref[2][k];
+            s_pref[0][k] = lo; s_pref[1][k] = lo + o0; s_pref[2][k] = lo + o0 + o1; s_pref[3][k] = lo + o0 + o1 + o2;
+            s_bsize[k] += lo;
+        }
+        __syncthreads();
+        if (table_wg) {
+            for (int k = t; k < nb; k += 256) bt.bsize[k] = s_bsize[k];
+            unit_tables<FB_MAX_UNITS>(bt, s_bsize, s_m, s_ro, s_x, sh, &s_maxm, pre);
+            return;
+        }
+        // the unit scan again, for this workgroup's own use: sizes, first rows, where the second block starts
+        if (t == 0) s_maxm = 0;
+        __syncthreads();
+        long long rows = 0, mat = 0;
+        for (int l0 = 0; l0 < bt.n_local; l0 += 256) {
+            int l = l0 + t;
+            int m = 0, mi = 0;
+            if (l < bt.n_local) {
+                int bi = l0 < 512 ? pre[0][l0 >> 8] : bt.unit_bi[l];
+                int bj = l0 < 512 ? pre[1][l0 >> 8] : bt.unit_bj[l];
+                mi = s_bsize[bi];
+                m = mi + (bj >= 0 ? s_bsize[bj] : 0);
+            }
+            long long mp = (m + 15) & ~15;
+            long long a = mp, b2 = mp * mp, ta, tb;
+            wg_exscan2(a, b2, sh, &ta, &tb);
+            if (l < bt.n_local) {
+                s_m[l] = m;
+                s_ro[l] = (int32_t)(rows + a);
+                s_x[l] = (unsigned)mi;
+                atomicMax(&s_maxm, m);
+            }
+            rows += ta;
+            mat += tb;
+        }
+        __syncthreads();
+        const int maxm = s_maxm;
+        over = rows > bt.cap_rows || mat > bt.cap_mat || (((maxm + 15) & ~15) >> 4) > bt.maxT_bound || maxm > MAX_MP;
+        // (a launch list outgrowing its grid is found by the table workgroup alone; the rows written here are inside the
+        // workspace all the same, and the evaluation is repeated)
+        // the units' padding rows (m .. mp) of the coordinate pool, dealt over the point workgroups
+        for (int idx = (int)blockIdx.x * 256 + t; !over && idx < bt.n_local * 16; idx += npw * 256) {
+            int u = idx >> 4, r = idx & 15;
+            int m = s_m[u];
+            if (m + r < ((m + 15) & ~15)) {
+                double *xr = bt.Xu + (size_t)(s_ro[u] + m + r) * bt.xstride;
+                for (int e = 0; e < bt.xstride; ++e) xr[e] = 0.0;
+            }
+        }
+    } else if (bt.ctl[CTL_OVERFLOW]) {
+        return;
+    }
+    if (p >= bt.n) return;
+    if (b < 0) {
+        if (rebuild) { bt.pe[2 * p] = 0; bt.pe[2 * p + 1] = 0; }
+        return;
+    }
+    if (rebuild) {
+        int pos = s_pref[t >> 6][b] + my_rank;
+        bt.posb[p] = pos;      // (also when the partition does not fit: the repeated evaluation builds from posb / bsize)
+        if (over) return;
+        scatter_rows(bt, X, dx, geo, p, e_first, e_end, pos, true, [&](int u, int side) { return s_ro[u] + (side ? (int)s_x[u] : 0); });
     } else {
-        r0 = X[(size_t)p * dx];
-        r1 = dx > 1 ? X[(size_t)p * dx + 1] : 0.0;
-        r2 = dx > 2 ? X[(size_t)p * dx + 2] : 0.0;
-        r3 = 0.0;
+        scatter_rows(bt, X, dx, geo, p, e_first, e_end, my_rank /* = posb */, false,
+                     [&](int u, int side) { return bt.row_off[u] + (side ? bt.off_j[u] : 0); });
     }
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    const int e_first = bt.bu_ptr[b], e_end = bt.bu_ptr[b + 1];
-    if (rebuild) { bt.pe[2 * p] = e_first; bt.pe[2 * p + 1] = e_end - e_first; }      // k_assemble's shortcuts
-    for (int e = e_first; e < e_end; ++e) {
-        int ent = bt.bu_ent[e];
-        int u = ent >> 1;
-        int row = bt.row_off[u] + ((ent & 1) ? bt.off_j[u] : 0) + pos;
-        if (rebuild) {
-            bt.upt[row] = p;
-            if (pos == 0) bt.ebase[e] = row;      // the block's first row inside this unit (one writer per entry)
-        }
-        d2v *dst = reinterpret_cast<d2v *>(bt.Xu + (size_t)row * (geo ? GEO_STRIDE : XPAD));      // 32- / 64-byte rows
-        dst[0] = d2v{r0, r1};
-        dst[1] = d2v{r2, r3};
-        if (geo) {
-            dst[2] = d2v{r4, 0.0};
-            dst[3] = d2v{0.0, 0.0};
-        }
-    }
+}
+
+// whether the single-launch form applies to this partition
+bool build_scatter_fits(const BuildTab &bt) {
+    static const bool off = [] { const char *e = getenv("GPRF_FUSED_BUILD"); return e && e[0] == '0'; }();
+    return !off && bt.n > 0 && bt.n_blocks > 0 && bt.n_blocks <= FB_MAX_BLOCKS && bt.n_local <= FB_MAX_UNITS &&
+           bt.n <= FB_MAX_POINTS;
+}
+void launch_build_scatter(const BuildTab &bt, const double *X, int dx, int dist_id, int force, int epoch, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_scatter, dim3((bt.n + 255) / 256 + 1), dim3(256), 0, s, bt, X, dx, dist_id == 1 ? 1 : 0, force, epoch);
 }
 
 void launch_build_tables(const BuildTab &bt, int from_chunks, int force, int epoch, hipStream_t s) {
