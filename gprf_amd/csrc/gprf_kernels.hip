@@ -1920,7 +1920,9 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 }
 
 // k_at_wide: the throughput form of k_at (many units per CU): one workgroup per 16 column tiles of the unit; wave w owns the column tiles
-// I = I0 + w, w+4, w+8, w+12 and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
+// I = I0 + w, 7-w, 8+w, 15-w (W is lower triangular: column tile I has T - I row tiles, and wave w always lands on SIMD w —
+// dealt w, w+4, w+8, w+12, wave 0 of every workgroup on a CU carried 40 tile steps of a 16-tile unit against wave 3's 28;
+// the snake gives 34 each) and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
 __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
@@ -1955,7 +1957,7 @@ __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
         const double *wrow = W + (size_t)(16 * kt + lg) * mp + lr;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            int I = I0 + wave + 4 * o;
+            int I = I0 + 4 * o + ((o & 1) ? 3 - wave : wave);
             if (I <= kt && I < T) {
                 double b[4];
 #pragma unroll
@@ -1969,7 +1971,7 @@ __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        int I = I0 + wave + 4 * o;
+        int I = I0 + 4 * o + ((o & 1) ? 3 - wave : wave);
         if (I < T) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
