@@ -120,6 +120,9 @@ struct gprf_ctx {
     template <typename T> struct View { T *p = nullptr; };
     View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
     View<double> d_ewgt;                  // per CSR entry: its unit's Bethe weight (static)
+    bool gxu_pending = false;             // the last evaluation left gXu to be made on demand (k_gx_finalize)
+    int gxu_want_gc = 0;
+    DevBuf<int32_t> d_einfo;              // k_assemble's per-entry (local first row, 64-point blocks) word
     DevBuf<int32_t> d_pe, d_ebase;        // k_assemble's per-point / per-entry shortcuts (k_scatter_x)
     DevBuf<int32_t> d_big_list, d_small_list;
     DevBuf<SlotRec> d_srec, d_big_rec, d_small_rec;
@@ -235,7 +238,7 @@ BuildTab make_build(gprf_ctx *c) {
     b.unit_bi = c->d_unit_bi.p; b.unit_bj = c->d_unit_bj.p; b.bu_ptr = c->d_bu_ptr.p; b.bu_ent = c->d_bu_ent.p;
     b.ids = c->d_ids.p; b.big_list = c->d_big_list.p; b.small_list = c->d_small_list.p;
     b.srec = c->d_srec.p; b.big_rec = c->d_big_rec.p; b.small_rec = c->d_small_rec.p;
-    b.pe = c->d_pe.p; b.ebase = c->d_ebase.p;
+    b.pe = c->d_pe.p; b.ebase = c->d_ebase.p; b.einfo = c->d_einfo.p;
     b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE && potrf_dual_enabled()) ? potrf_small_maxT() : 0;
     b.grid_big = c->grid_big; b.grid_small = c->grid_small;
     b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
@@ -428,6 +431,7 @@ int rebuild_static(gprf_ctx *c) {
     HIP_TRY(c, c->d_m.reserve(nl1));
     HIP_TRY(c, c->d_pe.reserve(2 * (size_t)c->n + 2, 1.0));
     HIP_TRY(c, c->d_ebase.reserve(bu_ent.size() + 1, 1.0));
+    HIP_TRY(c, c->d_einfo.reserve(bu_ent.size() + 1, 1.0));
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_offj.reserve(nl1));
     HIP_TRY(c, c->d_matoff.reserve(nl1));
@@ -636,9 +640,10 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     // host_io: d_X / d_out are the pinned host buffers themselves (read / written by the kernels over the fabric) and
     // the result words are mirrored into pinned memory by the assembly kernel: no copy command in the evaluation
     AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c),
-                   c->d_pe.p, c->d_ebase.p, c->d_ewgt.p,
+                   c->d_pe.p, c->d_ebase.p, c->d_einfo.p, 0, c->d_ewgt.p,
                    c->d_res.p, host_io ? c->h_res.d : nullptr, (int)c->res_words};
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
+    bool fold_gx = false;
     if (fused_build) launch_build_scatter(make_build(c), d_X, c->dx, c->dist_id, force, c->epoch, s);
     else launch_scatter_x(make_build(c), d_X, c->dx, c->dist_id, from_chunks, force, c->epoch, s);
     mark();
@@ -660,8 +665,16 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     if (do_grad) {
         launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
-        launch_gx_finalize(ut, pl, kp, want_gc, s);
+        // k_gx_finalize is a launch of its own for sums the assembly can do on the way (10 us of a 430 us evaluation) —
+        // up to GX_FOLD_MAX_UNITS units; beyond that the assembly's single summing workgroup would walk every unit's
+        // partials itself (C4: 106 us against 20).  The per-unit gradient (gprf_debug_fetch) is then made on demand.
+        static const bool fold_on = [] { const char *e = getenv("GPRF_GX_FOLD"); return !(e && e[0] == '0'); }();
+        fold_gx = fold_on && stop_after >= 5 && c->n_local <= GX_FOLD_MAX_UNITS;
+        if (!fold_gx) launch_gx_finalize(ut, pl, kp, want_gc, s);
+        c->gxu_pending = fold_gx;
+        c->gxu_want_gc = want_gc;
     }
+    at.fold_gx = fold_gx ? 1 : 0;
     mark();
     // gprf_objective: the result leaves in the optimiser's form; the location prior is added by ONE context of a
     // sharded job (rank 0), so that the all-reduce of the partial vectors counts it once
@@ -679,7 +692,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     c->poll_pending = false;
     const bool poll = host_io && stop_after >= 5 && c->spin && c->h_done.p;
     if (poll) c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
-    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, do_grad ? 1 : 0, ob, s);
+    if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, (do_grad && !fold_gx) ? 1 : 0, ob, s);
     mark();
     if (objective) {
         const double nel = (double)c->n * c->dx;
@@ -1062,7 +1075,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
     c->d_m.release(); c->d_rowoff.release(); c->d_offj.release(); c->d_upt.release(); c->d_assign.release();
-    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_pe.release(); c->d_ebase.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
+    c->d_posb.release(); c->d_rank.release(); c->d_big_list.release(); c->d_small_list.release(); c->d_srec.release(); c->d_big_rec.release(); c->d_small_rec.release(); c->d_pe.release(); c->d_ebase.release(); c->d_einfo.release(); c->d_cnt.release(); c->d_matoff.release(); c->d_res.release();
     c->h_res.release(); c->h_up.release();
     c->d_cs.release(); c->d_c2.release(); c->d_side.release(); c->d_Xobs.release(); c->d_xpart.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
@@ -1861,7 +1874,13 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
         case 1: src = c->d_W.p + c->l_matoff[l]; len = mp * mp; break;
         case 2: src = c->d_Z.p + roff * YPAD; len = mp * YPAD; break;
         case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;
-        case 4: src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;
+        case 4:
+            if (c->gxu_pending) {      // the evaluation folded the partials inside the assembly: the per-unit form now
+                launch_gx_finalize(make_tab(c), make_pools(c), make_kparams(c), c->gxu_want_gc, c->stream);
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->gxu_pending = false;
+            }
+            src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;
         case 6: src = c->d_dbg.p + (size_t)l * 8; len = 8; break;
 #ifdef GPRF_WGTRACE
         case 11: src = c->d_dbg.p + (size_t)std::max(c->n_local, 1) * 8; len = 4 * GPRF_WGTRACE_MAX; break;

@@ -74,6 +74,7 @@ struct BuildTab {
     int32_t *big_list, *small_list;   // [n_local] each: the units of more than / at most small_maxT tiles, in ids order
     SlotRec *srec, *big_rec, *small_rec;   // [n_local] each: the launch-slot records (UnitTab)
     int32_t *pe, *ebase;     // AssembleTab's per-point / per-entry shortcuts, rebuilt with the partition
+    int32_t *einfo;          // per entry: (the block's first row inside the unit, local) << 8 | the unit's 64-point blocks
     int small_maxT;          // 0 = no split
     int grid_big, grid_small;         // launch sizes the lists must fit
     int32_t *m;              // the UnitTab columns this build writes
@@ -140,6 +141,8 @@ struct AssembleTab {
     // that unit; the unit's Bethe weight): the point's rows in two dependent loads instead of four
     const int32_t *pe;         // [2 n], written by k_scatter_x with the partition
     const int32_t *ebase;      // [entries], written by k_scatter_x with the partition
+    const int32_t *einfo;      // [entries], likewise: (local row of the block's first point) << 8 | 64-point blocks of the unit
+    int fold_gx;               // 1: k_gx_finalize did not run — the gradient partials are folded here, per (point, unit)
     const double *ewgt;        // [entries], static
     // the context's result words [ctl | info | bsize] are mirrored by the assembly kernel into (host-visible) memory,
     // so that a host-in / host-out evaluation needs no copy command at all; mirror_dst = nullptr: no mirror
@@ -147,6 +150,8 @@ struct AssembleTab {
     int32_t *mirror_dst;
     int mirror_n;
 };
+
+constexpr int GX_FOLD_MAX_UNITS = 1024;      // local units up to which k_assemble folds the gradient partials itself
 
 // The optimiser-facing form of the result (gprf_objective; gprfopt.py:377-417): the assembly adds the location prior's
 // terms and flips the signs, so that what comes down in the evaluation's one download is what scipy's minimiser consumes.

@@ -2660,8 +2660,21 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
         if (k0 + e < cnt) {
             int row = at.ebase[e0 + k0 + e] + pos;      // = row_off[u] + (second block ? off_j[u] : 0) + pos
             double w = at.ewgt[e0 + k0 + e];            // = weight[u]
-            const double *gr = pl.gXu + (size_t)row * XPAD;
-            g0 = w * gr[0]; g1 = w * gr[1]; g2 = w * gr[2];
+            if (at.fold_gx) {
+                // k_gx_finalize's sum, here: the row's partials over the 64-point blocks of its unit, same order
+                const int info = at.einfo[e0 + k0 + e];
+                const int TB = info & 0xff, B = ((info >> 8) + pos) >> 6;
+                const int tbs = (ut.max_T + 3) >> 2;
+                const double *cp = pl.colpart + (size_t)row * tbs * XPAD;
+                const double *rp = pl.rowpart + (size_t)row * tbs * XPAD;
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                for (int IB = B; IB < TB; ++IB) { v0 += cp[IB * XPAD]; v1 += cp[IB * XPAD + 1]; v2 += cp[IB * XPAD + 2]; }
+                for (int JB = 0; JB <= B; ++JB) { v0 += rp[JB * XPAD]; v1 += rp[JB * XPAD + 1]; v2 += rp[JB * XPAD + 2]; }
+                g0 = w * v0; g1 = w * v1; g2 = w * v2;
+            } else {
+                const double *gr = pl.gXu + (size_t)row * XPAD;
+                g0 = w * gr[0]; g1 = w * gr[1]; g2 = w * gr[2];
+            }
         }
         term[i][e][0] = g0; term[i][e][1] = g1; term[i][e][2] = g2;
         __syncthreads();
@@ -3067,10 +3080,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
 }
 
 // one point's coordinate record into its row of every local unit that contains its block b (position pos inside the
-// block); row_of(unit, side) = the first row of that block inside the unit
-template <class RowOf>
+// block); unit_of(unit) = {row_off, off_j, m} of the unit
+struct UnitRows { int row_off, off_j, m; };
+template <class UnitOf>
 __device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double *__restrict__ X, int dx, int geo, int p,
-                                             int e_first, int e_end, int pos, bool rebuild, RowOf row_of) {
+                                             int e_first, int e_end, int pos, bool rebuild, UnitOf unit_of) {
     double r0, r1, r2, r3, r4 = 0.0;
     if (geo) {
         // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
@@ -3088,10 +3102,15 @@ __device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double *_
     for (int e = e_first; e < e_end; ++e) {
         int ent = bt.bu_ent[e];
         int u = ent >> 1;
-        int row = row_of(u, ent & 1) + pos;
+        const UnitRows ur = unit_of(u);
+        const int local0 = (ent & 1) ? ur.off_j : 0;
+        int row = ur.row_off + local0 + pos;
         if (rebuild) {
             bt.upt[row] = p;
-            if (pos == 0) bt.ebase[e] = row;      // the block's first row inside this unit (one writer per entry)
+            if (pos == 0) {      // the block's first row inside this unit (one writer per entry)
+                bt.ebase[e] = row;
+                bt.einfo[e] = (local0 << 8) | ((((ur.m + 15) >> 4) + 3) >> 2);
+            }
         }
         d2v *dst = reinterpret_cast<d2v *>(bt.Xu + (size_t)row * (geo ? GEO_STRIDE : XPAD));      // 32- / 64-byte rows
         dst[0] = d2v{r0, r1};
@@ -3140,7 +3159,7 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
     }
     if (bt.ctl[CTL_OVERFLOW]) return;
     scatter_rows(bt, X, dx, geo, p, bt.bu_ptr[b], bt.bu_ptr[b + 1], pos, rebuild,
-                 [&](int u, int side) { return bt.row_off[u] + (side ? bt.off_j[u] : 0); });
+                 [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], rebuild ? bt.m[u] : 0}; });
 }
 
 // k_build_scatter: k_build (both launches) and k_scatter_x as ONE launch for a partition that came from k_assign / k_route
@@ -3273,10 +3292,10 @@ __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double
         int pos = s_pref[t >> 6][b] + my_rank;
         bt.posb[p] = pos;      // (also when the partition does not fit: the repeated evaluation builds from posb / bsize)
         if (over) return;
-        scatter_rows(bt, X, dx, geo, p, e_first, e_end, pos, true, [&](int u, int side) { return s_ro[u] + (side ? (int)s_x[u] : 0); });
+        scatter_rows(bt, X, dx, geo, p, e_first, e_end, pos, true, [&](int u) { return UnitRows{s_ro[u], (int)s_x[u], s_m[u]}; });
     } else {
         scatter_rows(bt, X, dx, geo, p, e_first, e_end, my_rank /* = posb */, false,
-                     [&](int u, int side) { return bt.row_off[u] + (side ? bt.off_j[u] : 0); });
+                     [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], 0}; });
     }
 }
 
