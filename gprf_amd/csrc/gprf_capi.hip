@@ -120,6 +120,7 @@ struct gprf_ctx {
     template <typename T> struct View { T *p = nullptr; };
     View<int32_t> d_ids, d_unit_bi, d_unit_bj, d_bu_ptr, d_bu_ent;
     View<double> d_ewgt;                  // per CSR entry: its unit's Bethe weight (static)
+    int n_ent = 0;                        // entries of the block -> units CSR
     bool gxu_pending = false;             // the last evaluation left gXu to be made on demand (k_gx_finalize)
     int gxu_want_gc = 0;
     DevBuf<int32_t> d_einfo;              // k_assemble's per-entry (local first row, 64-point blocks) word
@@ -245,6 +246,7 @@ BuildTab make_build(gprf_ctx *c) {
     b.Xu = c->d_Xu.p; b.xstride = c->dist_id == GPRF_DIST_LLD ? 8 : XPAD;
     b.ctl = res_ctl(c);
     b.n = c->n; b.n_blocks = c->n_blocks; b.n_local = c->n_local; b.n_chunks = c->n_chunks;
+    b.n_ent = c->n_ent;
     b.cap_rows = c->cap_rows; b.cap_mat = c->cap_mat; b.maxT_bound = c->max_T;
     return b;
 }
@@ -432,6 +434,7 @@ int rebuild_static(gprf_ctx *c) {
     HIP_TRY(c, c->d_pe.reserve(2 * (size_t)c->n + 2, 1.0));
     HIP_TRY(c, c->d_ebase.reserve(bu_ent.size() + 1, 1.0));
     HIP_TRY(c, c->d_einfo.reserve(bu_ent.size() + 1, 1.0));
+    c->n_ent = (int)bu_ent.size();
     HIP_TRY(c, c->d_rowoff.reserve(nl1));
     HIP_TRY(c, c->d_offj.reserve(nl1));
     HIP_TRY(c, c->d_matoff.reserve(nl1));

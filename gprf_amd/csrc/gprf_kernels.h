@@ -86,6 +86,7 @@ struct BuildTab {
     int xstride;
     int32_t *ctl;            // control / result words, CTL_* below
     int n, n_blocks, n_local, n_chunks;
+    int n_ent;               // entries of the block -> units CSR (= bu_ptr[n_blocks])
     int64_t cap_rows, cap_mat;   // workspace capacities the build must stay within
     int maxT_bound;              // the launch-wide max_T the evaluation kernels will be launched with
 };

@@ -3082,25 +3082,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_build(BuildTab bt, int from_ch
 // one point's coordinate record into its row of every local unit that contains its block b (position pos inside the
 // block); unit_of(unit) = {row_off, off_j, m} of the unit
 struct UnitRows { int row_off, off_j, m; };
-template <class UnitOf>
-__device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double *__restrict__ X, int dx, int geo, int p,
-                                             int e_first, int e_end, int pos, bool rebuild, UnitOf unit_of) {
+// x = the point's raw coordinates (x[d] for d < dx), ent_of(e) = bu_ent[e]
+template <class UnitOf, class EntOf>
+__device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double (&x)[3], int geo, int p, int e_first, int e_end,
+                                             int pos, bool rebuild, UnitOf unit_of, EntOf ent_of) {
     double r0, r1, r2, r3, r4 = 0.0;
     if (geo) {
         // lld: (lon, lat, depth) -> half-angle record, see KernFn<1,1>
-        double lon = X[(size_t)p * dx], lat = X[(size_t)p * dx + 1], z = X[(size_t)p * dx + 2];
+        double lon = x[0], lat = x[1], z = x[2];
         double hl = lat * DEG2RAD / 2.0, hn = lon * DEG2RAD / 2.0;
         r0 = sin(hl); r1 = cos(hl); r2 = sin(hn); r3 = cos(hn); r4 = z;      // GEO_SLH, GEO_CLH, GEO_SNH, GEO_CNH, GEO_Z
     } else {
-        r0 = X[(size_t)p * dx];
-        r1 = dx > 1 ? X[(size_t)p * dx + 1] : 0.0;
-        r2 = dx > 2 ? X[(size_t)p * dx + 2] : 0.0;
-        r3 = 0.0;
+        r0 = x[0]; r1 = x[1]; r2 = x[2]; r3 = 0.0;
     }
     typedef double d2v __attribute__((ext_vector_type(2)));
     if (rebuild) { bt.pe[2 * p] = e_first; bt.pe[2 * p + 1] = e_end - e_first; }      // k_assemble's shortcuts
     for (int e = e_first; e < e_end; ++e) {
-        int ent = bt.bu_ent[e];
+        int ent = ent_of(e);
         int u = ent >> 1;
         const UnitRows ur = unit_of(u);
         const int local0 = (ent & 1) ? ur.off_j : 0;
@@ -3120,6 +3118,12 @@ __device__ __forceinline__ void scatter_rows(const BuildTab &bt, const double *_
             dst[3] = d2v{0.0, 0.0};
         }
     }
+}
+// the point's raw coordinates, unused dimensions 0
+__device__ __forceinline__ void load_point(const double *__restrict__ X, int dx, int p, double (&x)[3]) {
+    x[0] = X[(size_t)p * dx];
+    x[1] = dx > 1 ? X[(size_t)p * dx + 1] : 0.0;
+    x[2] = dx > 2 ? X[(size_t)p * dx + 2] : 0.0;
 }
 
 // k_scatter_x (every evaluation): a point's coordinate record into its row of every local unit that contains its
@@ -3158,8 +3162,11 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
         pos = bt.posb[p];
     }
     if (bt.ctl[CTL_OVERFLOW]) return;
-    scatter_rows(bt, X, dx, geo, p, bt.bu_ptr[b], bt.bu_ptr[b + 1], pos, rebuild,
-                 [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], rebuild ? bt.m[u] : 0}; });
+    double x[3];
+    load_point(X, dx, p, x);
+    scatter_rows(bt, x, geo, p, bt.bu_ptr[b], bt.bu_ptr[b + 1], pos, rebuild,
+                 [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], rebuild ? bt.m[u] : 0}; },
+                 [&](int e) { return bt.bu_ent[e]; });
 }
 
 // k_build_scatter: k_build (both launches) and k_scatter_x as ONE launch for a partition that came from k_assign / k_route
@@ -3169,8 +3176,9 @@ __global__ __launch_bounds__(256) void k_scatter_x(BuildTab bt, const double *__
 // histogram of the whole block assignment (n words, read once as int4: the block sizes, and how many points of each block
 // come before the workgroup's own 256), then the unit scan (sizes, row offsets) — and scatters its 256 points; one more
 // workgroup (the last) only writes the tables (unit_tables).  The redundant work is a few thousand integer operations per
-// workgroup.  Limits (else the three-launch path): FB_MAX_BLOCKS blocks, FB_MAX_UNITS local units, FB_MAX_POINTS points.
-constexpr int FB_MAX_BLOCKS = 1024, FB_MAX_UNITS = 2048, FB_MAX_POINTS = 1 << 15;
+// workgroup.  Limits (else the three-launch path): FB_MAX_BLOCKS blocks, FB_MAX_UNITS local units, FB_MAX_POINTS points,
+// FB_MAX_ENT entries of the block -> units CSR.
+constexpr int FB_MAX_BLOCKS = 1024, FB_MAX_UNITS = 2048, FB_MAX_POINTS = 1 << 15, FB_MAX_ENT = 4096;
 __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double *__restrict__ X, int dx, int geo, int force,
                                                        int epoch) {
     static_assert(SCAN_THREADS == 256 && CHUNK == 64, "four chunks per workgroup");
@@ -3179,48 +3187,71 @@ __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double
     __shared__ int s_lo[FB_MAX_BLOCKS], s_bsize[FB_MAX_BLOCKS], s_pref[4][FB_MAX_BLOCKS];
     __shared__ int s_m[FB_MAX_UNITS], s_ro[FB_MAX_UNITS];
     __shared__ unsigned s_x[FB_MAX_UNITS];      // table workgroup: mat_off >> 8; the others: off_j
-    const bool rebuild = rebuilding(bt, force, epoch);
+    __shared__ int s_buptr[FB_MAX_BLOCKS + 1], s_buent[FB_MAX_ENT];
     const int npw = (bt.n + 255) / 256;         // point workgroups; workgroup npw writes the tables
     const int t = threadIdx.x;
     const bool table_wg = (int)blockIdx.x == npw;
+    const int nb = bt.n_blocks, p0 = 256 * (int)blockIdx.x, n = bt.n;
+    const int p = p0 + t;
+    // Round trip 1 — everything that depends on nothing, asked for at once (each dependent load of this kernel is an
+    // exposed trip to HBM: with the control word, the point's block, the CSR range of the block and its entries read one
+    // after the other the kernel took 17.7 us): the control words, the point's own words and coordinates, the first batch
+    // of the assignment histogram, the unit scan's block ids, and the static block -> units CSR (into LDS).
+    const int ctl_changed = bt.ctl[CTL_CHANGED], ctl_over = bt.ctl[CTL_OVERFLOW];
+    const int b = p < n ? bt.assign[p] : -1;
+    const int rank_p = p < n ? bt.rank[p] : 0, posb_p = p < n ? bt.posb[p] : 0;
+    double x[3] = {0.0, 0.0, 0.0};
+    if (p < n) load_point(X, dx, p, x);
+    int pre[3][2] = {{0, 0}, {-1, -1}, {0, 0}};      // unit_bi, unit_bj, ids (the last for the table workgroup)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (t + 256 * q < bt.n_local) {
+            pre[0][q] = bt.unit_bi[t + 256 * q];
+            pre[1][q] = bt.unit_bj[t + 256 * q];
+            if (table_wg) pre[2][q] = bt.ids[t + 256 * q];
+        }
+    const int4 *a4 = reinterpret_cast<const int4 *>(bt.assign);
+    const int n4 = n >> 2;
+    int4 hv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hv[q] = t + 256 * q < n4 ? a4[t + 256 * q] : int4{-1, -1, -1, -1};
+    if (!table_wg) {
+        int bp[(FB_MAX_BLOCKS + 256) / 256], be[FB_MAX_ENT / 256];
+#pragma unroll
+        for (int q = 0; q < (FB_MAX_BLOCKS + 256) / 256; ++q) bp[q] = t + 256 * q <= nb ? bt.bu_ptr[t + 256 * q] : 0;
+#pragma unroll
+        for (int q = 0; q < FB_MAX_ENT / 256; ++q) be[q] = t + 256 * q < bt.n_ent ? bt.bu_ent[t + 256 * q] : 0;
+#pragma unroll
+        for (int q = 0; q < (FB_MAX_BLOCKS + 256) / 256; ++q)
+            if (t + 256 * q <= nb) s_buptr[t + 256 * q] = bp[q];
+#pragma unroll
+        for (int q = 0; q < FB_MAX_ENT / 256; ++q)
+            if (t + 256 * q < bt.n_ent) s_buent[t + 256 * q] = be[q];
+    }
+    const bool rebuild = force || ctl_changed == epoch;
     if (table_wg && !rebuild) return;
-    // the point's own words first (their round trips run under the scans below)
-    const int p = blockIdx.x * 256 + t;
-    const int b = p < bt.n ? bt.assign[p] : -1;
-    const int my_rank = p < bt.n ? (rebuild ? bt.rank[p] : bt.posb[p]) : 0;
-    const int e_first = b >= 0 ? bt.bu_ptr[b] : 0, e_end = b >= 0 ? bt.bu_ptr[b + 1] : 0;
     bool over = false;
     if (rebuild) {
-        const int nb = bt.n_blocks, p0 = 256 * (int)blockIdx.x, n = bt.n;
-        // (every global round trip of this kernel is exposed: what the unit scan needs is asked for now)
-        int pre[3][2] = {{0, 0}, {-1, -1}, {0, 0}};      // unit_bi, unit_bj, ids (the last for the table workgroup)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (t + 256 * q < bt.n_local) {
-                pre[0][q] = bt.unit_bi[t + 256 * q];
-                pre[1][q] = bt.unit_bj[t + 256 * q];
-                if (table_wg) pre[2][q] = bt.ids[t + 256 * q];
-            }
         for (int k = t; k < nb; k += 256) {
             s_lo[k] = 0; s_bsize[k] = 0;        // (s_bsize: the points from p0 on, until the two are added)
             s_pref[0][k] = 0; s_pref[1][k] = 0; s_pref[2][k] = 0; s_pref[3][k] = 0;
         }
         __syncthreads();
         {
-            const int4 *a4 = reinterpret_cast<const int4 *>(bt.assign);
-            const int n4 = n >> 2;
-            for (int i0 = t; i0 < n4; i0 += 8 * 256) {      // eight loads in flight per thread
+            auto count = [&](const int4 &v, int idx) {
+                const int bb[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bb[k] >= 0) atomicAdd(idx + k < p0 ? &s_lo[bb[k]] : &s_bsize[bb[k]], 1);
+            };
+#pragma unroll
+            for (int q = 0; q < 8; ++q) count(hv[q], 4 * (t + 256 * q));
+            for (int i0 = t + 8 * 256; i0 < n4; i0 += 8 * 256) {      // (more than 8192 points: eight loads in flight per thread)
                 int4 v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = i0 + 256 * q < n4 ? a4[i0 + 256 * q] : int4{-1, -1, -1, -1};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int idx = 4 * (i0 + 256 * q);
-                    const int bb[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (bb[k] >= 0) atomicAdd(idx + k < p0 ? &s_lo[bb[k]] : &s_bsize[bb[k]], 1);
-                }
+                for (int q = 0; q < 8; ++q) count(v[q], 4 * (i0 + 256 * q));
             }
             if (4 * n4 + t < n) {
                 int bb = bt.assign[4 * n4 + t];
@@ -3280,22 +3311,25 @@ __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double
                 for (int e = 0; e < bt.xstride; ++e) xr[e] = 0.0;
             }
         }
-    } else if (bt.ctl[CTL_OVERFLOW]) {
-        return;
+    } else {
+        if (ctl_over) return;
+        __syncthreads();      // the CSR copy in LDS
     }
-    if (p >= bt.n) return;
+    if (p >= n) return;
     if (b < 0) {
         if (rebuild) { bt.pe[2 * p] = 0; bt.pe[2 * p + 1] = 0; }
         return;
     }
+    const int e_first = s_buptr[b], e_end = s_buptr[b + 1];
     if (rebuild) {
-        int pos = s_pref[t >> 6][b] + my_rank;
+        int pos = s_pref[t >> 6][b] + rank_p;
         bt.posb[p] = pos;      // (also when the partition does not fit: the repeated evaluation builds from posb / bsize)
         if (over) return;
-        scatter_rows(bt, X, dx, geo, p, e_first, e_end, pos, true, [&](int u) { return UnitRows{s_ro[u], (int)s_x[u], s_m[u]}; });
+        scatter_rows(bt, x, geo, p, e_first, e_end, pos, true, [&](int u) { return UnitRows{s_ro[u], (int)s_x[u], s_m[u]}; },
+                     [&](int e) { return s_buent[e]; });
     } else {
-        scatter_rows(bt, X, dx, geo, p, e_first, e_end, my_rank /* = posb */, false,
-                     [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], 0}; });
+        scatter_rows(bt, x, geo, p, e_first, e_end, posb_p, false, [&](int u) { return UnitRows{bt.row_off[u], bt.off_j[u], 0}; },
+                     [&](int e) { return s_buent[e]; });
     }
 }
 
@@ -3303,7 +3337,7 @@ __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double
 bool build_scatter_fits(const BuildTab &bt) {
     static const bool off = [] { const char *e = getenv("GPRF_FUSED_BUILD"); return e && e[0] == '0'; }();
     return !off && bt.n > 0 && bt.n_blocks > 0 && bt.n_blocks <= FB_MAX_BLOCKS && bt.n_local <= FB_MAX_UNITS &&
-           bt.n <= FB_MAX_POINTS;
+           bt.n <= FB_MAX_POINTS && bt.n_ent <= FB_MAX_ENT;
 }
 void launch_build_scatter(const BuildTab &bt, const double *X, int dx, int dist_id, int force, int epoch, hipStream_t s) {
     hipLaunchKernelGGL(k_build_scatter, dim3((bt.n + 255) / 256 + 1), dim3(256), 0, s, bt, X, dx, dist_id == 1 ? 1 : 0, force, epoch);
