@@ -20,8 +20,8 @@ def short(name):
         return "k_potrf_reg_gen" if (", true>" in name or "ELb1E" in name) else "k_potrf_reg"
     if "k_mgrad" in name and ("<0, 0, true>" in name or "ILi0ELi0ELb1E" in name):
         return "k_mgrad_readK"
-    for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
-              "k_assign", "k_route", "k_build", "k_scatter_x", "k_done", "k_pair_max"):
+    for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at_wide", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
+              "k_assign", "k_route", "k_build_scatter", "k_build", "k_scatter_x", "k_done", "k_finish", "k_pair_max"):
         if k in name:
             return k
     return name[:40]

@@ -1,0 +1,65 @@
+"""The launch variants of one evaluation agree bit for bit: the single-launch table build (k_build_scatter) against
+the three-launch one (k_build x 2 + k_scatter_x), the gradient partials folded inside the assembly against a
+k_gx_finalize launch, the Cholesky as two instantiations on two queues against one queue.  The switches are read
+once per process (diagnostic environment variables), so every variant runs in its own interpreter on the same seeded
+walk — points cross block borders at every step, so the tables are rebuilt on the device each time — and prints a
+digest of everything the walk returned."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+DRIVER = r'''
+import hashlib, sys
+import numpy as np
+from gprf_amd import Blocker, grid_centers, GPCov
+from gprf_amd.gprf import GPRF
+
+rng = np.random.RandomState(31)
+n = 1500
+X = rng.rand(n, 2)
+Y = rng.randn(n, 7)
+b = Blocker(grid_centers(16))
+g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.09, 0.11], "euclidean", "se"), 0.02, neighbors=b.neighbors())
+h = hashlib.sha256()
+moved = 0
+for it in range(6):
+    Xn = np.clip(X + 0.03 * rng.randn(n, 2), 0.0, 1.0)
+    before = [len(u) for u in g.block_idxs]
+    g.update_X(Xn)
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=(it % 2 == 0))
+    moved += before != [len(u) for u in g.block_idxs]
+    h.update(np.float64(ll).tobytes()); h.update(np.ascontiguousarray(gX).tobytes()); h.update(np.ascontiguousarray(gC).tobytes())
+    for u in g.block_idxs:
+        h.update(np.ascontiguousarray(u, dtype=np.int64).tobytes())
+    X = Xn
+assert moved >= 4, moved
+g.close()
+print("DIGEST", h.hexdigest())
+'''
+
+
+def run_variant(tmp_path, extra_env):
+    (tmp_path / "driver.py").write_text(DRIVER)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, str(tmp_path / "driver.py")], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("DIGEST ")]
+    assert len(lines) == 1, out[-3000:]
+    return lines[0].split()[1]
+
+
+def test_launch_variants_agree_bit_for_bit(tmp_path):
+    base = run_variant(tmp_path, {})
+    for name, env in (("three-launch table build", {"GPRF_FUSED_BUILD": "0"}),
+                      ("k_gx_finalize as a launch", {"GPRF_GX_FOLD": "0"}),
+                      ("one Cholesky queue", {"GPRF_POTRF_DUAL": "2"})):
+        assert run_variant(tmp_path, env) == base, name
