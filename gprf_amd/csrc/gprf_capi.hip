@@ -1743,33 +1743,6 @@ const char *gprf_build_flags(void) {
 #ifdef GPRF_WGTRACE
            " GPRF_WGTRACE"
 #endif
-#ifdef GPRF_ABL
-           " GPRF_ABL"
-#endif
-#ifdef GPRF_ABL_NOFACTOR
-           " GPRF_ABL_NOFACTOR"
-#endif
-#ifdef GPRF_ABL_NODUMP
-           " GPRF_ABL_NODUMP"
-#endif
-#ifdef GPRF_ABL_NOSUBST
-           " GPRF_ABL_NOSUBST"
-#endif
-#ifdef GPRF_ABL_NOCOPY
-           " GPRF_ABL_NOCOPY"
-#endif
-#ifdef GPRF_ABL_NOTRAIL
-           " GPRF_ABL_NOTRAIL"
-#endif
-#ifdef GPRF_ABL_NOEPI
-           " GPRF_ABL_NOEPI"
-#endif
-#ifdef GPRF_ABL_MG_NOMMA
-           " GPRF_ABL_MG_NOMMA"
-#endif
-#ifdef GPRF_ABL_MG_NOEPI
-           " GPRF_ABL_MG_NOEPI"
-#endif
 #ifdef GPRF_MGRAD_FINE
            " GPRF_MGRAD_FINE"
 #endif

@@ -1135,12 +1135,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         double s[16], dk, rdk;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = Dt[jt * 256 + r * 16 + lr];
-#ifndef GPRF_ABL_NOFACTOR
         int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
-#else
-        int bad = 0;
-        dk = rdk = s[3];
-#endif
         if (lane < 16) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) Ud[i * 16 + lr] = s[i];   // the factor left 0 below the diagonal
@@ -1329,9 +1324,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
     };
     for (int j = 0; j + 1 < T; ++j) {
-#ifndef GPRF_ABL
         if (s_fail) break;
-#endif
         // keep the per-slot tile coordinates and LDS addresses from being hoisted out of the step loop (they are
         // loop invariant, and 18 slots of them would push the accumulators out of the register file)
         int lb = lg * ldp + lr;
@@ -1350,7 +1343,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
         if (mine) {
             // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
-#ifndef GPRF_ABL_NODUMP
             // (static walk in groups of 8 slots, like the trailing chain: the slot number must be a compile-time
             // constant for the register numbers; a group costs one compare when none of its slots is in range)
             static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
@@ -1374,7 +1366,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                     });
                 }
             });
-#endif
             __builtin_amdgcn_wave_barrier();
             GPRF_STAMP2(0)
             // lane row lg solves the lg-th of them (a second pass only when the wave holds more than four tiles
@@ -1390,7 +1381,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                 double uc[3] = {Gd[lr], Gd[16 + lr], 0.0};   // row c of G = D^-1 U_jj, fetched two rows ahead
                 double rc[3] = {rdt[0], rdt[1], 0.0};        // 1 / U_cc: the same for every lane (LDS broadcast read)
                 GPRF_STAMP2(1)
-#ifndef GPRF_ABL_NOSUBST
                 // unit triangular G: ONE fused multiply-add per step on the chain (row c+1 first); row c, final by now, is
                 // scaled by 1 / U_cc into a copy that goes straight to the panel — off the chain, between the other updates
                 static_for<0, 16>([&](auto cc) {
@@ -1406,10 +1396,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                         fnma_bcast16_ordered<a>(x[a], uc[c % 3], x[c]);
                     });
                 });
-#else
-#pragma unroll
-                for (int a = 0; a < 16; ++a) P[a * ldp + col] = x[a];
-#endif
                 GPRF_STAMP2(2)
               }
             }
@@ -1427,14 +1413,12 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         if (mine) {
             // the solved row panel -> global U first when wave 0 is a worker too: the stores retire under the
             // MFMA work below
-#ifndef GPRF_ABL_NOCOPY
             if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution ...
             else if (copy_now) copy_panel(j, wave - 1, RW - 1);      // ... or, single-buffered, the three workers now)
             GPRF_STAMP3(0)
             // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % NW
             if (wave > 0)
                 for (int i = j + 2 + (wave - 1 + NW * T - (j + 2)) % NW; i < T; i += NW) diag_update(i);
-#endif
             GPRF_STAMP3(1)
             // live tiles: slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS panel
             // before slot S's four MFMAs issue
@@ -1448,7 +1432,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                     ob[t] = Pk[(4 * t) * ldp];
                 }
             };
-#ifndef GPRF_ABL_NOTRAIL
             if (s_hi < s_end) {
                 // walked from the LAST slot down: the slot index stays a compile-time constant (register numbers)
                 // in straight-line code, the dead slots (below s_hi) are never visited, and one compare per tile
@@ -1498,7 +1481,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                     if (S == s_hi) atile_add<S>(tt[S & 1]);
                 });
             }
-#endif
         }
         GPRF_STAMP(2)
         GPRF_STAMP2(5)
@@ -1540,9 +1522,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     }
     if (!copy_now && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
     __syncthreads();    // the epilogue reads U_jj back from global
-#ifndef GPRF_ABL_NOEPI
     potrf_epilogue<RW>(U, V, P0, dvals, lred, mp, T, u, pl);
-#endif
 #ifdef GPRF_PROFILE
     if (stamp && lane == 0) {   // [5] prologue, [6] epilogue cycles
         pl.dbg[(size_t)u * 8 + 5] = (double)(t_loop - t_start);
@@ -2237,13 +2217,11 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
         GPRF_SST2(1)
         // the -dy of the W part rides on the A operand (4 multiplies per chunk): the accumulators are never
         // rescaled in the middle of the chunk loop
-#ifndef GPRF_ABL_MG_NOMMA
         if (c < nchW) {
             if (active && (4 * IB + c) >= I) mma_chunk(buf, -dyd);
         } else {
             if (active) mma_chunk(buf, 1.0);       // (the last chunk's rows beyond dy are zero padding)
         }
-#endif
         GPRF_SST2(2)
     };
 #ifdef GPRF_PROFILE
@@ -2305,11 +2283,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     // the wave's diagonal tile (diagonal block pairs only; it is tile jj == wrow): k re-evaluated from the
     // coordinates (the pool holds U there), column sums only
     double csd[3] = {0.0, 0.0, 0.0};
-#ifdef GPRF_ABL_MG_NOEPI
-    const bool epi = kp.dy < 0;                        // (never: the reductions are compiled but skipped)
-#else
     constexpr bool epi = true;
-#endif
     if (epi && active && diagblk) {                    // wave-uniform
         d4 md = wrow == 0 ? acc[0] : (wrow == 1 ? acc[1] : (wrow == 2 ? acc[2] : acc[3]));
         int j = 16 * I + lr;
