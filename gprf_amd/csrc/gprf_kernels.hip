@@ -1905,10 +1905,15 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 // the snake gives 34 each) and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
-__global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int first_round) {
     int slot_, part_;
     WgTrace trace(ut, pl, 2);
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    // A launch of at most two workgroups per CU is resident all at once: workgroup first_round + j (first_round = the CUs)
+    // becomes the second resident of the CU that took workgroup j.  The launch order is largest unit first, so the CU of the
+    // largest unit also got the largest of the rest, and the launch lasted as long as those two sharing four SIMDs; with the
+    // second round in ASCENDING size the largest unit is paired with the smallest.
+    if (first_round > 0 && slot_ >= first_round) slot_ = ut.n_ids - 1 - (slot_ - first_round);
     const UnitRef ur = unit_ref(ut.srec, slot_);
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
@@ -3535,7 +3540,12 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (!wide)
         hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
     else
-        hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p);
+    {
+        static const bool rev = [] { const char *e = getenv("GPRF_AT_REVERSE"); return !(e && e[0] == '0'); }();
+        const int cus = device_cus();
+        const int first_round = (rev && ut.max_T <= 16 && ut.n_ids > cus && ut.n_ids <= 2 * cus) ? cus : 0;
+        hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round);
+    }
 }
 
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s) {
