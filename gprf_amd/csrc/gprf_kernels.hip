@@ -107,6 +107,17 @@ struct WgTrace {
 #endif
 };
 
+// The same grid walked part by part: all units' part 0, then all units' part 1, ... (a unit's workgroups still land on one
+// XCD: the slot count is padded to a multiple of 8).  For launches several rounds of workgroups deep whose parts differ in
+// length: with the longest kind of part first across ALL units the launch order is longest-first by workgroup, not by unit,
+// and the tail of the launch is made of short workgroups.
+__device__ __forceinline__ bool part_major_map(int linear, int n_ids, int nparts, int *slot, int *part) {
+    int n8 = (n_ids + 7) & ~7;
+    *part = linear / n8;
+    *slot = linear - *part * n8;
+    (void)nparts;
+    return *slot < n_ids;
+}
 __device__ __forceinline__ bool xcd_map(int linear, int n_ids, int nparts, int *slot, int *part) {
     int grp = linear / (8 * nparts);
     int rem = linear - grp * (8 * nparts);
@@ -1673,7 +1684,7 @@ constexpr int SOLVE_PANEL_MAXT = 28;  // largest k_solve_panel instantiation (ac
 // — four RHS column blocks — share every U tile and each update MFMA costs one conflict-free ds_read.
 // Each wave's tiles for all rows stay in MFMA accumulators; the freshly solved tile is already in B-operand layout
 // (accumulator register q = rows 4q+lg), so the right-looking updates chain through registers.
-template <int MAXT, int WPS>
+template <int MAXT, int WPS, bool PM>
 __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, int dy) {
     // panel columns are stored RELATIVE to the first column right of the diagonal tile (16(r+1)): a step loads and
     // keeps only what its updates read.  (LDP/16) odd: lane groups 32 banks apart
@@ -1687,7 +1698,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 #ifdef GPRF_PROFILE
     unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (!xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_)) return;
+    if (!(PM ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_) : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
     // the Y workgroup (every step, a gather in front) is the longest of a unit: it is dispatched first
     part_ = part_ == 0 ? nI : part_ - 1;
     const UnitRef ur = unit_ref(ut.srec, slot_);
@@ -2088,7 +2099,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
 template <int DIST, int KERN, bool HAVEK, int FAST>
-__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc) {
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
     // reductions at the end find them in LDS instead of starting with exposed global loads
@@ -2096,7 +2107,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     int TBm = (ut.max_T + 3) >> 2;
     int slot, bp;
     WgTrace trace(ut, pl, 3);
-    if (!xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp)) return;
+    // (part_major: every unit's block pair 0 first, then every unit's pair 1, ...: pairs are in order of descending length)
+    if (!(part_major ? part_major_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp) : xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp))) return;
     const UnitRef ur = unit_ref(ut.srec, slot);
     int u = ur.u;
     int m = ur.m;
@@ -3519,11 +3531,21 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
 
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0) return;
+    // PM: the grid walked part by part (part_major_map) — launches several rounds deep; GPRF_PART_MAJOR=0 / 1 forces
+    static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool pm = pm_env >= 0 ? pm_env == 1 : ut.n_ids <= 2 * device_cus();
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
         dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
-        if (ut.max_T <= 12) hipLaunchKernelGGL((k_solve_panel<12, 3>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        else if (ut.max_T <= 18) hipLaunchKernelGGL((k_solve_panel<18, 2>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        if (ut.max_T <= 12) {
+            if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 18) {
+            if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else {
+            if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        }
         return;
     }
     // units of more than 448 points: accumulators no longer fit the register budget -> LDS-broadcast form
@@ -3558,21 +3580,25 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     int TBm = (ut.max_T + 3) / 4;
     dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
+    static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // (only while the launch is a few rounds deep: with thousands of units the ten workgroups of a unit would run far apart
+    // and each fetch the unit's W / At from HBM again — C4: 809 vs 775 us)
+    const int pm = pm_env >= 0 ? pm_env : (ut.n_ids <= 2 * device_cus() ? 1 : 0);
     if (dist_id == 0 && kern_id == 0) {
         // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
         int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
         if (const char *e = getenv("GPRF_MGRAD_FAST")) { if (e[0] == '0') fast = 0; }      // diagnostics: general form
         if (have_K) {
-            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, true, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, true, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
         } else {
-            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, false, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, false, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
         }
     } else {
-        hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc);
+        hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
     }
 }
 

@@ -62,5 +62,6 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
     for name, env in (("three-launch table build", {"GPRF_FUSED_BUILD": "0"}),
                       ("k_gx_finalize as a launch", {"GPRF_GX_FOLD": "0"}),
                       ("one Cholesky queue", {"GPRF_POTRF_DUAL": "2"}),
-                      ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"})):
+                      ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"}),
+                      ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"})):
         assert run_variant(tmp_path, env) == base, name
