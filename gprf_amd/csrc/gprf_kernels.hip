@@ -1559,6 +1559,14 @@ template <int RW, int SLOTS, bool GEN>
 __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
     potrf_reg_body<RW, SLOTS, GEN, 1>(ut, pl, stamps, reg_maxT, kp, which);
 }
+// eight waves of 256 registers, ONE workgroup per CU (seven workers x 20 slots: every unit of up to 16 tiles): a unit
+// finishes 20 % sooner than with four waves of 512 registers (T = 15: 89 vs 104-113 us) — as the only kernel it loses (a
+// whole CU per unit: 140 vs 123 us), as the kernel of the LARGEST units, which are what the stage waits for, it is in
+template <int SLOTS, bool GEN>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8(UnitTab ut, Pools pl, int stamps,
+                                                                                           int reg_maxT, KParams kp, int which) {
+    potrf_reg_body<8, SLOTS, GEN, 2>(ut, pl, stamps, reg_maxT, kp, which);
+}
 template <int RW, int SLOTS, bool GEN>
 __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg2(UnitTab ut, Pools pl, int stamps,
                                                                                                 int reg_maxT, KParams kp, int which) {
@@ -3475,7 +3483,15 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
                 // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
                 // the grids follow the list lengths of the last synchronised partition with a little slack)
-                if (ut.grid_big > 0)
+                static const bool big8 = [] { const char *e = getenv("GPRF_POTRF_BIG8"); return !(e && e[0] == '0'); }();
+                if (ut.grid_big > 0 && big8) {
+                    size_t lds8 = (size_t)(16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
+                    if (lds_needs_optin(4, lds8))
+                        (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                    hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, true>), dim3(ut.grid_big), dim3(512), lds8, s, utb, p, stamps,
+                                       reg_maxT, kp, 1);
+                } else if (ut.grid_big > 0)
                     hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
                                        dim3(POTRF_REG_WAVES * 64), lds, s, utb, p, stamps, reg_maxT, kp, 1);
                 if (fork_kernel) {

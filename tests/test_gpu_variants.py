@@ -21,7 +21,7 @@ from gprf_amd import Blocker, grid_centers, GPCov
 from gprf_amd.gprf import GPRF
 
 rng = np.random.RandomState(31)
-n = 1500
+n = 1800          # 16 blocks of ~112 points: pairs of 13-15 tiles per edge (both Cholesky classes)
 X = rng.rand(n, 2)
 Y = rng.randn(n, 7)
 b = Blocker(grid_centers(16))
@@ -63,5 +63,6 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("k_gx_finalize as a launch", {"GPRF_GX_FOLD": "0"}),
                       ("one Cholesky queue", {"GPRF_POTRF_DUAL": "2"}),
                       ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"}),
-                      ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"})):
+                      ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"}),
+                      ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"})):
         assert run_variant(tmp_path, env) == base, name

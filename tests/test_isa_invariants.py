@@ -39,9 +39,10 @@ def _setting(lines, mangled_part, key):
     raise AssertionError("no .set %s for %s" % (key, mangled_part))
 
 
-# K read / K generated (512 registers per wave, 32 tile slots); K generated, two workgroups per CU (256 registers, 20 slots)
+# K read / K generated (512 registers per wave, 32 tile slots); K generated, two workgroups per CU (256 registers, 20 slots);
+# K generated, eight waves of 256 registers (the largest units)
 @pytest.mark.parametrize("inst,slots", [("11k_potrf_regILi4ELi32ELb0E", 32), ("11k_potrf_regILi4ELi32ELb1E", 32),
-                                        ("12k_potrf_reg2ILi4ELi20ELb1E", 20)])
+                                        ("12k_potrf_reg2ILi4ELi20ELb1E", 20), ("12k_potrf_reg8ILi20ELb1E", 20)])
 def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa, inst, slots):
     body = _function(isa, inst)
     inasm, outside, stubs = False, [], 0
