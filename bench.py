@@ -391,7 +391,7 @@ def main():
             tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             # (the Cholesky stage is two kernels side by side: their traffic adds up)
             # (whichever of a stage's kernels ran: the wide or the narrow At kernel; k_gx_finalize only where it is launched)
-            keys = {"potrf": ("k_potrf_reg_gen", "k_potrf_reg2_gen"), "solve": ("k_solve_panel",), "at": ("k_at", "k_at_wide"),
+            keys = {"potrf": ("k_potrf_reg_gen", "k_potrf_reg8_gen", "k_potrf_reg2_gen"), "solve": ("k_solve_panel",), "at": ("k_at", "k_at_wide"),
                     "grad": ("k_mgrad", "k_gx_finalize"), "fill": ("k_fill",)}[dom]
             keys = tuple(k_ for k_ in keys if k_ in tr)
             if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:

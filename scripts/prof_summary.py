@@ -16,6 +16,8 @@ def short(name):
     # the two instantiations that differ by where K comes from (demangled or mangled spelling)
     if "k_potrf_reg2" in name:
         return "k_potrf_reg2_gen"
+    if "k_potrf_reg8" in name:
+        return "k_potrf_reg8_gen"
     if "k_potrf_reg" in name:
         return "k_potrf_reg_gen" if (", true>" in name or "ELb1E" in name) else "k_potrf_reg"
     if "k_mgrad" in name and ("<0, 0, true>" in name or "ILi0ELi0ELb1E" in name):
