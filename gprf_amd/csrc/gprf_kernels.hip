@@ -2933,14 +2933,22 @@ __device__ __forceinline__ bool rebuilding(const BuildTab &bt, int force, int ep
 constexpr int SCAN_THREADS = 256;
 
 // exclusive prefix sums of a and b over the workgroup; returns the totals through ta / tb
+// inclusive prefix sum over the 64 lanes of a wave, in registers: four row shifts and two row broadcasts (DPP) — through
+// __shfl_up it is six rounds of ds_bpermute, and with two 64-bit values per call 24 dependent LDS round trips
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source keep 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+// (a, b: non-negative, at most 2^20 each — a unit's padded size and its square — so the sums of one call fit 32 bits)
 __device__ __forceinline__ void wg_exscan2(long long &a, long long &b, long long *sh /* LDS [2][4] */, long long *ta,
                                            long long *tb) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long ia = a, ib = b;
-    for (int off = 1; off < 64; off <<= 1) {
-        long long ua = __shfl_up(ia, off, 64), ub = __shfl_up(ib, off, 64);
-        if (lane >= off) { ia += ua; ib += ub; }
-    }
+    long long ia = wave_incl_scan((int)a), ib = wave_incl_scan((int)b);
     if (lane == 63) { sh[wave] = ia; sh[4 + wave] = ib; }
     __syncthreads();
     long long pa = 0, pb = 0, sa = 0, sb = 0;
@@ -2962,6 +2970,7 @@ template <int M_LDS>
 __device__ __forceinline__ void unit_tables(const BuildTab &bt, const int *bsz, int *s_m, int *s_ro, unsigned *s_mo,
                                             long long *sh /* LDS [8] */, int *s_maxm_p /* LDS */, const int (*pre)[2] = nullptr) {
     int t = threadIdx.x;
+    const int builds_before = t == 0 ? bt.ctl[CTL_BUILDS] : 0;      // (asked for now: at the end it would be one more exposed round trip)
     if (t == 0) *s_maxm_p = 0;
     __syncthreads();
     long long rows = 0, mat = 0;
@@ -3042,7 +3051,7 @@ __device__ __forceinline__ void unit_tables(const BuildTab &bt, const int *bsz, 
         bt.ctl[CTL_MAXM] = maxm;
         bt.ctl[CTL_MAT_LO] = (int32_t)(mat & 0xffffffffll);
         bt.ctl[CTL_MAT_HI] = (int32_t)(mat >> 32);
-        bt.ctl[CTL_BUILDS] += 1;
+        bt.ctl[CTL_BUILDS] = builds_before + 1;
     }
 }
 
@@ -3555,7 +3564,7 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
         if (ut.max_T <= 12) {
             if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        } else if (ut.max_T <= 18) {
+        } else if (ut.max_T <= 18) {      // (an exact 16-tile instantiation is slower: 82 vs 79 us, C4 674 vs 640)
             if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else {
