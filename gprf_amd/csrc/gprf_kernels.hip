@@ -758,11 +758,16 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
             d4 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = Cii[(size_t)(4 * q) * mp];
+            // (the step's 16 products from zero, then ONE addition into the running tile — the hierarchical accumulation of
+            // the register kernels, see above k_potrf_reg: this kernel factors the units of more than 256 points and the
+            // lld / Matérn ones, and was left with the sequential order and its 1.2x LAPACK's error)
+            d4 sacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 double a = P[(4 * s + lg) * ldp + 16 * i + lr];
-                acc = mfma(-a, a, acc);
+                sacc = mfma(-a, a, sacc);
             }
+            acc += sacc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) Tt[(lg + 4 * q) * 17 + lr] = acc[q];
             __builtin_amdgcn_wave_barrier();    // same wave, LDS is in order: the reads below see the tile
@@ -794,8 +799,10 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
 #pragma unroll
                             for (int q = 0; q < 4; ++q) nxt[q] = Rik[(size_t)(4 * q) * mp + 16];
                         }
+                        d4 t16 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) cur = mfma(a[s], Pk[(4 * s) * ldp], cur);
+                        for (int s = 0; s < 4; ++s) t16 = mfma(a[s], Pk[(4 * s) * ldp], t16);
+                        cur += t16;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) Cik[(size_t)(4 * q) * mp] = cur[q];
                         Cik += 16;
