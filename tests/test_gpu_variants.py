@@ -20,11 +20,12 @@ import numpy as np
 from gprf_amd import Blocker, grid_centers, GPCov
 from gprf_amd.gprf import GPRF
 
+import os
 rng = np.random.RandomState(31)
-n = 1800          # 16 blocks of ~112 points: pairs of 13-15 tiles per edge (both Cholesky classes)
+n = int(os.environ.get("VAR_N", "1800"))          # 16 blocks of ~112 points: pairs of 13-15 tiles per edge (both Cholesky classes)
 X = rng.rand(n, 2)
 Y = rng.randn(n, 7)
-b = Blocker(grid_centers(16))
+b = Blocker(grid_centers(int(os.environ.get("VAR_BLOCKS", "16"))))
 g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.09, 0.11], "euclidean", "se"), 0.02, neighbors=b.neighbors())
 h = hashlib.sha256()
 moved = 0
@@ -55,6 +56,14 @@ def run_variant(tmp_path, extra_env):
     lines = [l for l in out.splitlines() if l.startswith("DIGEST ")]
     assert len(lines) == 1, out[-3000:]
     return lines[0].split()[1]
+
+
+def test_single_launch_table_build_with_many_blocks(tmp_path):
+    """400 blocks (more than one per thread of a workgroup), 1900 units, 3400 CSR entries: inside k_build_scatter's limits,
+    beyond the assembly's fold (k_gx_finalize runs)"""
+    shape = {"VAR_N": "4000", "VAR_BLOCKS": "400"}
+    base = run_variant(tmp_path, shape)
+    assert run_variant(tmp_path, dict(shape, GPRF_FUSED_BUILD="0")) == base
 
 
 def test_launch_variants_agree_bit_for_bit(tmp_path):
