@@ -659,7 +659,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         side.s2 = c->stream2; side.ev_fork = c->ev_fork; side.ev_join = c->ev_join;
         side.words = c->side_values ? c->d_side.p : nullptr;
         side.seq = ++c->side_seq;
-        launch_potrf(ut, pl, kp, gen, s, side);
+        launch_potrf(ut, pl, kp, gen, c->dist_id == 1 ? 1 : 0, s, side);
     }
     mark();
     if (stop_after >= 2) launch_solve(ut, pl, kp, s);

@@ -198,7 +198,8 @@ struct SideQueue {
     uint32_t *words = nullptr;      // [3] device words: fork, join, fork written by the large-unit kernel itself
     uint32_t seq = 0;               // value of this evaluation (monotonic)
 };
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side);
+// dk (gen only): 0 = SE, 1 = lld / Matérn-3/2
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,

@@ -966,7 +966,9 @@ constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13
 // tiles per edge, one workgroup per CU); 2 = 256 registers per wave (20 tile slots + 96 VGPRs: units up to 13 tiles per
 // edge, TWO workgroups per CU — a unit's factorisation is a latency chain that keeps its SIMDs a quarter busy, so
 // two of them side by side nearly double the CU's throughput).  Units outside [min_T, reg_maxT] are left alone.
-template <int RW, int SLOTS, bool GEN, int WPS>
+// DK (GEN only): 0 = ("euclidean","se"), coordinates of XPAD doubles per point; 1 = ("lld","matern32"), the GEO_STRIDE-double
+// half-angle records (KernFn<1,1>::value per entry, k_fill<1,1>'s definition)
+template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0>
 __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &pl, int stamps, int reg_maxT, const KParams &kp,
                                                int which) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
@@ -1089,12 +1091,28 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     atile_reserve<SLOTS>();
     // GEN: K(row, col) of this unit, exactly k_fill's definition (identity in the padding, noise + jitter on the
     // diagonal); the unit's coordinates wait in LDS
-    double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XPAD], GEN only (the launcher sizes the LDS)
+    double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XS], GEN only (the launcher sizes the LDS)
+    constexpr int XS = DK == 1 ? GEO_STRIDE : XPAD;
     const double diag_add = kp.nv + ut.jitter[u];
     // NT tiles (pk = 32 * tile row + tile column) side by side, branch-free: this wave is alone on its SIMD, so the
     // only thing that hides the latency of one exp()'s dependent chain is the other 4 NT - 1 evaluations
     auto kgen = [&](auto ntc, const int *pk, double (*out)[4], double sign) {
         constexpr int NT = decltype(ntc)::value;
+        if constexpr (DK == 1) {
+            // great-circle / Matérn-3/2: entry by entry (haversine, asin, two square roots, exp: nothing to vectorise by hand)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int col = 16 * (pk[t] & 31) + lr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int row = 16 * (pk[t] >> 5) + 4 * q + lg;
+                    double v = KernFn<1, 1>::value(kp, xs + row * XS, xs + col * XS) + (row == col ? diag_add : 0.0);
+                    if (!(row < m && col < m)) v = (row == col) ? 1.0 : 0.0;
+                    out[t][q] = sign * v;
+                }
+            }
+            return;
+        }
         double sq[NT * 4], e[NT * 4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1126,8 +1144,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
     };
     if constexpr (GEN) {
-        const double *Xu = pl.Xu + (size_t)ur.row_off * XPAD;
-        for (int e = threadIdx.x; e < mp * XPAD; e += RW * 64) xs[e] = Xu[e];
+        const double *Xu = pl.Xu + (size_t)ur.row_off * XS;
+        for (int e = threadIdx.x; e < mp * XS; e += RW * 64) xs[e] = Xu[e];
         __syncthreads();
     }
     // diagonal tiles -> LDS
@@ -1569,6 +1587,11 @@ __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, 
 // eight waves of 256 registers, ONE workgroup per CU (seven workers x 20 slots: every unit of up to 16 tiles): a unit
 // finishes 20 % sooner than with four waves of 512 registers (T = 15: 89 vs 104-113 us) — as the only kernel it loses (a
 // whole CU per unit: 140 vs 123 us), as the kernel of the LARGEST units, which are what the stage waits for, it is in
+// ("lld","matern32") units of up to 16 tiles per edge, K generated (round 3): the seismic configuration's unary blocks
+template <int RW, int SLOTS>
+__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg_lld(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
+    potrf_reg_body<RW, SLOTS, true, 1, 1>(ut, pl, stamps, reg_maxT, kp, which);
+}
 template <int SLOTS, bool GEN>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8(UnitTab ut, Pools pl, int stamps,
                                                                                            int reg_maxT, KParams kp, int which) {
@@ -3401,7 +3424,13 @@ static bool potrf_use_reg(const UnitTab &ut) {
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
     const bool off = e && e[0] == '0';
-    return !off && dist_id == 0 && kern_id == 0 && ut.n_ids > 0 && potrf_use_reg(ut);
+    // ("lld","matern32") generation is built and tested but OFF by default: on the seismic configuration's shape the unary
+    // blocks' kernel then spends 90 us generating (haversine + asin + two square roots + exp per entry, four lone waves)
+    // in front of the generic kernel instead of 52 us reading — fill 77 -> 64 us, Cholesky stage 250 -> 289 us.
+    // GPRF_LLD_GEN=1 turns it on.
+    static const bool lld_gen = [] { const char *g = getenv("GPRF_LLD_GEN"); return g && g[0] == '1'; }();
+    const bool se = dist_id == 0 && kern_id == 0, lld = dist_id == 1 && kern_id == 1 && lld_gen;
+    return !off && (se || lld) && ut.n_ids > 0 && potrf_use_reg(ut);
 }
 int potrf_gen_maxT() { return POTRF_REG_MAXT_C; }
 
@@ -3413,7 +3442,7 @@ bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation 
 }
 int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
 
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side) {
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side) {
     if (ut.n_ids == 0) return;
     hipStream_t s2 = side.s2;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
@@ -3435,6 +3464,18 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
         size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        if (gen && dk == 1) {
+            // ("lld","matern32"): one instantiation over every unit of up to 16 tiles (no size classes: the class lists are
+            // built for the SE path only); larger units were filled and go to the generic kernel
+            lds += (size_t)(16 * capT * GEO_STRIDE) * sizeof(double);
+            if (lds_needs_optin(5, lds))
+                (void)hipFuncSetAttribute((const void *)k_potrf_reg_lld<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_potrf_reg_lld<POTRF_REG_WAVES, POTRF_REG_SLOTS>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
+                               ut, p, stamps, reg_maxT, kp, 0);
+            launch_generic();
+            return;
+        }
         if (gen) {
             lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
             // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the

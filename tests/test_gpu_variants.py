@@ -75,3 +75,42 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"}),
                       ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"})):
         assert run_variant(tmp_path, env) == base, name
+
+
+LLD_DRIVER = r'''
+import sys
+import numpy as np
+from gprf_amd import GPCov
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(7)
+n = 900
+X = np.column_stack([rng.uniform(100.0, 104.0, n), rng.uniform(30.0, 33.0, n), rng.uniform(0.0, 40.0, n)])
+Y = rng.randn(n, 5)
+order = np.argsort(X[:, 0])
+blocks = [np.sort(order[i:i + 150]) for i in range(0, n, 150)]          # six blocks of 150 events
+nbrs = [(i, i + 1) for i in range(5)]                                    # pairs of 300: the generic kernel
+g = GPRF(X, Y, None, GPCov([2.0], [60.0, 25.0], "lld", "matern32"), 0.05, block_idxs=blocks, neighbors=nbrs)
+ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
+g.close()
+'''
+
+
+def test_lld_matern_generated_equals_filled(tmp_path):
+    """("lld","matern32"): the unary blocks' kernel matrices generated inside the register Cholesky (GPRF_LLD_GEN=1) against
+    filled into the K pool and read (the default): the same entries by the same arithmetic"""
+    (tmp_path / "lld.py").write_text(LLD_DRIVER)
+    out = {}
+    for tag, env in (("fill", {}), ("gen", {"GPRF_LLD_GEN": "1"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        e.update(env)
+        r = subprocess.run([sys.executable, str(tmp_path / "lld.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        import numpy as np
+        out[tag] = np.load(str(tmp_path / (tag + ".npz")))
+    import numpy as np
+    a, b = out["fill"], out["gen"]
+    assert abs(float(a["ll"]) - float(b["ll"])) <= 1e-13 * abs(float(a["ll"]))
+    assert np.max(np.abs(a["gX"] - b["gX"])) <= 1e-11 * np.max(np.abs(a["gX"]))
+    assert np.allclose(a["gC"], b["gC"], rtol=1e-11)
