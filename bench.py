@@ -241,6 +241,11 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # next to the GPU: the zero-copy evaluation is 25-55 % slower from the other socket of a two-socket box, and which socket a
+    # process starts on is the scheduler's choice (gprf_amd/numa.py; GPRF_NUMA_PIN=0 leaves the affinity alone)
+    from gprf_amd import numa
+    affinity_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa_node, numa_cpus = numa.pin_to_gpu_node(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("GPRF_FORCE_ALLREDUCE") == "1":   # the latter: exercise the RCCL path on one GPU
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -430,7 +435,9 @@ def main():
                                "sequential, one synchronisation per evaluation",
                        "parallelism": ("units sharded over %d device(s) driven by ONE process; partial sums meet on device 0 (peer "
                                        "stores + one summing kernel)" % len(devices)) if devices is not None else
-                                      "units sharded over %d rank(s), 1 all-reduce/eval" % world},
+                                      "units sharded over %d rank(s), 1 all-reduce/eval" % world,
+                       "host": ("process pinned to the GPU's NUMA node %d (%d cpus)" % (numa_node, numa_cpus)) if numa_node >= 0
+                               else "CPU affinity left as found"},
             "roofline": roof,
             **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks / members time-share one GPU; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
@@ -551,6 +558,8 @@ def main():
         g5.close()
 
     if world == 1 and not args.only_north_star and not args.no_cpu_baseline:
+        if affinity_before is not None:
+            os.sched_setaffinity(0, affinity_before)      # the CPU baseline may use every core of the box
         result["cpu_baseline"] = cpu_baseline(sd, args.local_dist, args.cpu_seconds, grad_cov)
         result["speedup_vs_cpu_port"] = value / result["cpu_baseline"]["value"]
         if result["cpu_baseline"].get("pool_value"):

@@ -244,3 +244,19 @@ def test_candidate_block_pairs_cover_the_exhaustive_oracle_list(dfn):
         if thr >= 1e-3 and max(ls) < 1000:
             assert len(cand) < 0.5 * nb * (nb - 1) / 2
     assert total > 50
+
+
+def test_numa_pin_is_a_no_op_without_a_gpu_and_parses_cpu_lists(tmp_path, monkeypatch):
+    """gprf_amd.numa: no GPU (or no NUMA information) -> nothing is changed; GPRF_NUMA_PIN=0 -> nothing is changed"""
+    import os
+    from gprf_amd import numa
+    before = os.sched_getaffinity(0)
+    import torch
+    if not torch.cuda.is_available():
+        assert numa.gpu_numa_node(0) == -1
+        assert numa.pin_to_gpu_node(0) == (-1, 0)
+    monkeypatch.setenv("GPRF_NUMA_PIN", "0")
+    assert numa.pin_to_gpu_node(0) == (-1, 0)
+    assert os.sched_getaffinity(0) == before
+    if os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        assert len(numa._node_cpus(0)) >= 1
