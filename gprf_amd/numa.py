@@ -1,9 +1,8 @@
 """Run next to the GPU.  The sequential evaluation is zero-copy: the kernels read X from, and write the result and the
-completion word into, pinned host memory, and the host polls that word.  On a two-socket box a process that happens to run
-(and first-touch its pinned buffers) on the socket the GPU does NOT hang off was measured 25-55 % slower per evaluation
-(0.51-0.61 ms against 0.39) — the scheduler decides per process, so the same command is fast or slow
-from run to run.  `pin_to_gpu_node` narrows the calling process's CPU affinity to the cores of the GPU's NUMA node (what
-`numactl --cpunodebind` would do from outside); call it before the first `GPRF(...)` is built."""
+completion word into, pinned host memory, and the host polls that word.  `pin_to_gpu_node` narrows the calling process's CPU
+affinity to the cores of the GPU's NUMA node (what `numactl --cpunodebind` would do from outside); call it before the first
+`GPRF(...)` is built.  Measured on the MI355X pool: no difference on most boxes, 0.51-0.61 ms against 0.39 per evaluation
+on one ("Run-to-run spread") — cheap insurance, not a cure for every slow run."""
 import os
 
 
