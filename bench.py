@@ -13,6 +13,11 @@ host, all-reduce included when N > 1 — before the next one starts.  Steps cycl
 L-BFGS-B iterates: every step re-partitions).  `value` = steps / wall time of that sequential loop.
 N > 1 ("strong" scaling): the SAME evaluation's units are sharded over the ranks (LPT on m^3 + 4 m^2 dy); every rank
 holds X, Y, theta; each evaluation ends with a single RCCL all-reduce of 1 + n*dx + ncov (+2 status) doubles.
+`python bench.py --gpus N` (no launcher) starts that N-rank job ITSELF, as a child process (torch.distributed.run, one rank
+per GPU) before this process touches the GPU, relays rank 0's line and adds the single-process figure
+(gprf_create_multi: one process, N devices) from a second child; under torch.distributed.run it is one of the ranks.
+`value` = steps / the MEDIAN wall time of REPS repetitions of the timed loop (every repetition: exactly --steps
+evaluations between barrier + synchronize; all samples in "ms_per_step_samples").
 
 Rank 0 prints ONE JSON line.  Extra keys: "roofline" (dominant kernel, HIP-event timed inside the timed region),
 "cpu_baseline" (the oracle's CPU port on this box's host cores), "stages_ms", "device_resident_evals_per_s" (the
@@ -39,6 +44,7 @@ FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profi
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 STAGE_PASS_EVALS = 60     # evaluations of the separate pass that times every kernel of every evaluation
+REPS = 7                  # repetitions of the timed loop; `value` is their median (a slow leg shows in the samples, not in the headline)
 
 
 def source_hash():
@@ -77,6 +83,9 @@ def parse():
                     help="diagnostic: skip the separate per-kernel timing pass (no roofline then)")
     ap.add_argument("--source-hash", action="store_true", help="print the native sources' hash (profile_run.sh) and exit")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--reps", type=int, default=REPS, help="repetitions of the timed loop (value = median)")
+    ap.add_argument("--no-single-process-leg", action="store_true",
+                    help="self-launched N > 1 run: skip the second child (one process driving the N devices)")
     return ap.parse_args()
 
 
@@ -212,11 +221,68 @@ def git_head():
         return None
 
 
+def _last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                return json.loads(line)
+            except ValueError:
+                pass
+    return None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: THIS process never touches the GPU (no torch import, no HIP call) — it
+    starts the N-rank job as a child (`python -m torch.distributed.run --nproc-per-node N bench.py ...`: one rank per GPU,
+    one RCCL all-reduce per evaluation, the north-star design), relays rank 0's JSON line and exits with the child's code;
+    a second child times the single-process form (gprf_create_multi) and its figure rides along as an extra key."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    me = os.path.abspath(__file__)
+    argv = [a for a in sys.argv[1:] if a != "--no-single-process-leg"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), me] + argv
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    line = _last_json_line(r.stdout or "")
+    if r.returncode != 0 or line is None:
+        sys.stdout.write(r.stdout or "")
+        sys.exit(r.returncode if r.returncode != 0 else 1)
+    line["launched_by"] = "bench.py itself: child `python -m torch.distributed.run --nproc-per-node %d` (%.0f s)" % (
+        args.gpus, time.perf_counter() - t0)
+    if not args.no_single_process_leg:
+        sp = {"value": None}
+        try:
+            cmd2 = [sys.executable, me, "--single-process", "--only-north-star", "--no-cpu-baseline"] + argv
+            r2 = subprocess.run(cmd2, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+            l2 = _last_json_line(r2.stdout or "")
+            if r2.returncode == 0 and l2 is not None:
+                sp = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"],
+                      "ms_per_step_samples": l2.get("ms_per_step_samples"), "parallelism": l2["config"]["parallelism"],
+                      "group": l2["config"].get("group")}
+            else:
+                sp["error"] = "rc %d: %s" % (r2.returncode, (r2.stderr or "")[-400:])
+        except Exception as e:      # a side figure: never lose the headline over it
+            sp["error"] = repr(e)
+        line["single_process"] = sp
+        line["single_process_evals_per_s"] = sp["value"]
+    print(json.dumps(line))
+    sys.exit(0)
+
+
 def main():
     args = parse()
     if args.source_hash:
         print(source_hash())
         return
+    if (args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ
+            and "LOCAL_RANK" not in os.environ):
+        launch_ranks(args)      # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,9 +293,7 @@ def main():
         # (GPRF_BENCH_ONE_GPU=1: N logical members on GPU 0 — exercises the path on a one-GPU box, the numbers mean nothing)
         devices = [0] * args.gpus if os.environ.get("GPRF_BENCH_ONE_GPU") == "1" else list(range(args.gpus))
     elif world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world       # under a launcher the launcher's world size is the truth
 
     import torch
     import torch.distributed as dist
@@ -282,25 +346,30 @@ def main():
         sd.set_centers(grid_centers(nblocks))
         return sd
 
-    def sequential_rate(g, Xlist, steps, warmup, grad_cov):
+    def sequential_rate(g, Xlist, steps, warmup, grad_cov, reps=1):
         """THE metric's loop: update_X + llgrad, one evaluation finished before the next starts, nothing else in the
-        timed region (no events); -> (evals/s, ms)"""
+        timed region (no events).  `reps` repetitions, each EXACTLY `steps` evaluations between barrier + synchronize
+        (max over ranks); -> (evals/s at the median repetition, its ms per step, ms per step of every repetition)"""
         nXl = len(Xlist)
         for k in range(warmup):
             g.update_X(Xlist[k % nXl])
             g.llgrad(grad_X=True, grad_cov=grad_cov)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            g.update_X(Xlist[k % nXl])
-            g.llgrad(grad_X=True, grad_cov=grad_cov)
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return steps / el, 1e3 * el / steps
+        samples = []
+        for _ in range(max(1, reps)):
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                g.update_X(Xlist[k % nXl])
+                g.llgrad(grad_X=True, grad_cov=grad_cov)
+            barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            samples.append(el)
+        el = float(np.median(samples))
+        return steps / el, 1e3 * el / steps, [1e3 * e / steps for e in samples]
 
     # ---------------- inputs
     ntrain = args.ntrain
@@ -344,11 +413,31 @@ def main():
     # ---------------- the timed region: the reference's GPRF object, sharded over the ranks
     g = (sd.build_gprf(local_dist=args.local_dist, devices=devices) if devices is not None else
          sd.build_gprf(local_dist=args.local_dist, device=local_rank, shard=(rank, world)))
-    value, ms_per_step = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov)
+    n_members = len(devices) if devices is not None else world      # devices working on ONE evaluation
+    value, ms_per_step, ms_samples = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov, args.reps)
+    # who really took part: ranks of the collective's backend, devices this process sees, units per shard
+    if devices is not None:
+        nm, on_host, devs_used, shard_units = g._ctx.group_info()
+        group_info = {"members": nm, "devices": devs_used, "partials_meet": "pinned host memory (no peer access)" if on_host
+                      else "fine-grained memory of device %d (peer stores)" % devs_used[0]}
+        backend, rccl_ranks = None, None
+    else:
+        group_info = None
+        nloc = g._ctx.num_units()[1]
+        if world > 1:
+            tl = torch.zeros(world, dtype=torch.int64, device=dev)
+            tl[rank] = nloc
+            dist.all_reduce(tl)
+            shard_units = [int(v) for v in tl.tolist()]
+            backend = dist.get_backend()
+            rccl_ranks = dist.get_world_size() if backend == "nccl" else 0
+        else:
+            shard_units, backend, rccl_ranks = [nloc], None, None
     if args.no_stage_timing:
         if rank == 0:
             print(json.dumps({"diagnostic": "headline only (no per-kernel timing pass)", "value": value,
-                              "unit": "evals/s", "ms_per_step": ms_per_step, "n_gpus": world}))
+                              "unit": "evals/s", "ms_per_step": ms_per_step, "n_gpus": n_members,
+                              "ms_per_step_samples": [round(v, 5) for v in ms_samples], "library": _capi.runtime_config()}))
         g.close()
         if dist.is_initialized():
             dist.barrier()
@@ -399,7 +488,7 @@ def main():
             keys = {"potrf": ("k_potrf_reg_gen", "k_potrf_reg8_gen", "k_potrf_reg2_gen"), "solve": ("k_solve_panel",), "at": ("k_at", "k_at_wide"),
                     "grad": ("k_mgrad", "k_gx_finalize"), "fill": ("k_fill",)}[dom]
             keys = tuple(k_ for k_ in keys if k_ in tr)
-            if world == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
+            if n_members == 1 and args.ntrain == 10000 and args.nblocks == 100 and args.local_dist < 1.0:
                 if tr.get("source_hash") == source_hash():
                     roof["traffic"] = sum(tr[k_]["bytes_per_launch"] for k_ in keys)
                     roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these sources, hash %s)" % (
@@ -420,12 +509,19 @@ def main():
         roof["worst"] = {"kernel": "k_" + wk, "frac": roof["all_stages"][wk]["frac"]}
         roof["mfma_f64_measured_peak"] = FP64_MFMA_MEASURED_TFLOPS
         kernels_ms = sum(stage[s] for s in stage)
-        roof["whole_eval_TFLOPs_kernels"] = total_all / (kernels_ms * 1e-3) / 1e12 if world == 1 else None
-        roof["whole_eval_frac_of_fp64_peak_kernels"] = (total_all / (kernels_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if world == 1 else None
+        # (stage times are rank 0's / member 0's kernels — 1 / n_members of the units: every figure that divides the WHOLE
+        # evaluation's work or wall time by them is defined only when one device does all of it)
+        roof["whole_eval_TFLOPs_kernels"] = total_all / (kernels_ms * 1e-3) / 1e12 if n_members == 1 else None
+        roof["whole_eval_frac_of_fp64_peak_kernels"] = (total_all / (kernels_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if n_members == 1 else None
+        roof["stages_of"] = "the only device" if n_members == 1 else "shard 0 of %d (its share of the units, its kernels)" % n_members
         result = {
             "metric": "GPRF objective+gradient evals/sec, n=%d nblocks=%d yd=%d" % (ntrain, args.nblocks, args.yd),
-            "value": value, "unit": "evals/s", "n_gpus": len(devices) if devices is not None else world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": n_members, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "repetitions": len(ms_samples), "ms_per_step_samples": [round(v, 5) for v in ms_samples],
+            "value_is": "steps / median wall time over the repetitions (each: exactly `steps` evaluations between barrier + synchronize)",
+            "rccl_ranks": rccl_ranks, "collective_backend": backend, "devices_seen": torch.cuda.device_count(),
+            "shard_units": shard_units,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "n=%d nblocks=%d yd=%d lscale=%g obs_std=%g local_dist=%g (%d unary + %d pair units) task=%s"
                                    % (ntrain, args.nblocks, args.yd, args.lscale, args.obs_std, args.local_dist,
@@ -437,7 +533,8 @@ def main():
                                        "stores + one summing kernel)" % len(devices)) if devices is not None else
                                       "units sharded over %d rank(s), 1 all-reduce/eval" % world,
                        "host": ("process pinned to the GPU's NUMA node %d (%d cpus)" % (numa_node, numa_cpus)) if numa_node >= 0
-                               else "CPU affinity left as found"},
+                               else "CPU affinity left as found",
+                       "group": group_info, "library": _capi.runtime_config()},
             "roofline": roof,
             **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks / members time-share one GPU; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
@@ -445,7 +542,7 @@ def main():
             "stage_timing": "separate pass behind the timed region: %d sequential evaluations with HIP events between the kernels "
                             "of every one (%.4f ms per evaluation with the events; the headline has none); 'gather' includes "
                             "the re-partition and table-build kernels" % (cnt, ms_with_events),
-            "host_gap_ms": round(ms_per_step - kernels_ms, 5),
+            "host_gap_ms": round(ms_per_step - kernels_ms, 5) if n_members == 1 else None,
         }
 
     # ---------------- secondary figures
@@ -460,7 +557,7 @@ def main():
         barrier()
         if rank == 0:
             result["llgrad_only_evals_per_s"] = 50.0 / (time.perf_counter() - t1)
-    if world == 1 and not args.only_north_star:
+    if n_members == 1 and not args.only_north_star:
         # the kernels' own rate: the same evaluations enqueued back to back on one stream, X / result resident in HBM,
         # no host synchronisation inside the loop (one context per distinct X, its tables built beforehand)
         run_stream = torch.cuda.Stream(device=dev)
@@ -500,7 +597,7 @@ def main():
             ev.g.close()
         # BASELINE configs[1]: no pairs
         gl = sd.build_gprf(local_dist=1.0, device=local_rank)
-        result["local_gp_evals_per_s"] = sequential_rate(gl, Xlist, 100, 10, grad_cov)[0]
+        result["local_gp_evals_per_s"] = sequential_rate(gl, Xlist, 100, 10, grad_cov, 3)[0]
         gl.close()
     g.close()
 
@@ -511,13 +608,13 @@ def main():
               sd4.build_gprf(local_dist=0.5, device=local_rank, shard=(rank, world)))
         rng = np.random.RandomState(1)
         X4 = [np.ascontiguousarray(sd4.X_obs + 0.25 * sd4.obs_std * k * rng.randn(*sd4.X_obs.shape)) for k in range(3)]
-        c4, c4ms = sequential_rate(g4, X4, 30, 5, True)
+        c4, c4ms, c4samples = sequential_rate(g4, X4, 30, 5, True, 3)
         if rank == 0:
             s4 = gdist.unit_sizes(sd4.block_idxs, sd4.neighbors)
             result["c4_evals_per_s"] = c4
             result["c4"] = {"workload": "n=80000 nblocks=800(841) yd=50 lscale=0.02 obs_std=0.002 local_dist=0.5 (841 unary + %d pair "
                                         "units) task=xcov, prior draw by dense fp64 Cholesky at N=80500 on the GPU" % len(sd4.neighbors),
-                            "ms_per_eval": c4ms, "steps": 30, "distinct_X": 3,
+                            "ms_per_eval": c4ms, "steps": 30, "distinct_X": 3, "ms_per_eval_samples": [round(v, 4) for v in c4samples],
                             "algorithmic_TFLOPs": algorithmic_flops(s4, 50)["total"] * c4 / 1e12}
         g4.close()
         del sd4
@@ -535,7 +632,7 @@ def main():
         g5 = GPRF(X5, Y5, reblock5, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6, **kw5)
         rng5 = np.random.RandomState(2)
         X5s = [np.ascontiguousarray(X5 + 1e-4 * k * rng5.randn(*X5.shape)) for k in range(3)]
-        c5, c5ms = sequential_rate(g5, X5s, 40, 5, True)
+        c5, c5ms, c5samples = sequential_rate(g5, X5s, 40, 5, True, 3)
         g5._ctx.set_timing(True, reset=True)
         for k in range(12):
             g5.update_X(X5s[k % 3])
@@ -551,13 +648,13 @@ def main():
             result["c5"] = {"workload": "STAND-IN catalogue (synthetic_events, n=%d), lld / matern32, split-tree blocks < 210 (%d blocks), "
                                         "threshold 0.6 (%d pairs, largest unit %d points), yd=50, task xcov" % (
                                             n5, len(g5.block_idxs), len(g5.neighbors), int(sz5.max())),
-                            "ms_per_eval": c5ms, "steps": 40, "distinct_X": 3,
+                            "ms_per_eval": c5ms, "steps": 40, "distinct_X": 3, "ms_per_eval_samples": [round(v, 4) for v in c5samples],
                             "stages_ms": {k2: round(v, 5) for k2, v in st5.items()},
                             "algorithmic_TFLOPs": fl5["total"] * c5 / 1e12,
-                            "fill_GBps": (fl5["fill_bytes"] / (st5["fill"] * 1e-3) / 1e9) if (world == 1 and st5["fill"] > 0) else None}
+                            "fill_GBps": (fl5["fill_bytes"] / (st5["fill"] * 1e-3) / 1e9) if (n_members == 1 and st5["fill"] > 0) else None}
         g5.close()
 
-    if world == 1 and not args.only_north_star and not args.no_cpu_baseline:
+    if n_members == 1 and not args.only_north_star and not args.no_cpu_baseline:
         if affinity_before is not None:
             os.sched_setaffinity(0, affinity_before)      # the CPU baseline may use every core of the box
         result["cpu_baseline"] = cpu_baseline(sd, args.local_dist, args.cpu_seconds, grad_cov)

@@ -62,6 +62,8 @@ SIGNATURES = {
     "gprf_hyper_unpack": (ctypes.c_int, [_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i32, _dp, _dp]),
     "gprf_hyper_grad": (ctypes.c_int, [_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i32, _dp, _dp, _dp, _dp]),
     "gprf_build_flags": (ctypes.c_char_p, []),
+    "gprf_runtime_config": (ctypes.c_char_p, []),
+    "gprf_group_info": (ctypes.c_int, [_vp, _i32p, _i32p, _i32, _i32p, _i32p]),
     "gprf_debug_run": (ctypes.c_int, [_vp, _dp, _i32]),
     "gprf_debug_fetch": (ctypes.c_int, [_vp, _i32, _i32, _dp, ctypes.c_int64]),
     "gprf_debug_unit_shape": (ctypes.c_int, [_vp, _i32, _i32p, _i32p, _i32p]),
@@ -130,6 +132,11 @@ def _preload_torch_hip_runtime():
 def build_flags():
     """diagnostic defines the loaded library was compiled with ("" = the product build)"""
     return load().gprf_build_flags().decode().split()
+
+
+def runtime_config():
+    """the launch structure the loaded library runs with in this environment (gprf_runtime_config) as a dict of strings"""
+    return dict(kv.split("=", 1) for kv in load().gprf_runtime_config().decode().split())
 
 
 def partition_units(m, dy, world):
@@ -212,9 +219,9 @@ class Context(object):
             rc = self.lib.gprf_create(ctypes.byref(self.h), n, dx, dy, dist_id, kern_id, device)
         if rc != GPRF_OK:
             self.h = None
-            raise GprfHipError("gprf_create failed (%d): no usable HIP device %s, or unsupported "
-                               "shape/kernel (n=%d dx=%d dy=%d dist=%d kern=%d)" % (rc, devices if devices is not None else device,
-                                                                                 n, dx, dy, dist_id, kern_id))
+            raise GprfHipError("gprf_create%s failed (%d): %s (device(s) %s, n=%d dx=%d dy=%d dist=%d kern=%d)" % (
+                "_multi" if devices is not None else "", rc, self.lib.gprf_last_error(None).decode(),
+                devices if devices is not None else device, n, dx, dy, dist_id, kern_id))
         self.n, self.dx, self.dy = n, dx, dy
         self.ncov = 2 + (dx if dist_id == 0 else 2)
 
@@ -396,6 +403,14 @@ class Context(object):
         r = _i32(0)
         self._check(self.lib.gprf_last_reblocked(self.h, ctypes.byref(r)), "gprf_last_reblocked")
         return bool(r.value)
+
+    def group_info(self):
+        """-> (members, slots_on_host, [device ordinal per member], [units per member]) of a multi-device group"""
+        nm, oh = _i32(0), _i32(0)
+        devs, units = np.zeros(64, dtype=np.int32), np.zeros(64, dtype=np.int32)
+        self._check(self.lib.gprf_group_info(self.h, ctypes.byref(nm), ctypes.byref(oh), 64, devs.ctypes.data_as(_i32p),
+                                             units.ctypes.data_as(_i32p)), "gprf_group_info")
+        return nm.value, bool(oh.value), devs[:nm.value].tolist(), units[:nm.value].tolist()
 
     def num_units(self):
         a, b = _i32(0), _i32(0)

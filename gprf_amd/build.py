@@ -39,21 +39,45 @@ def build(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = "%s.tmp.%d" % (LIB, os.getpid())
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
-           "-Wl,--no-undefined",      # a symbol one source file declares and the other forgot to define fails HERE
-           # k_potrf_reg keeps tiles in explicitly numbered AGPRs behind inline asm: the compiler must never park a
-           # spilled VGPR in an AGPR of its own choosing (tests/test_isa_invariants.py checks the ISA)
-           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-           "-o", tmp] + [os.path.join(CSRC, f) for f in SOURCES]
+def _flags():
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-pthread",
+             # k_potrf_reg keeps tiles in explicitly numbered AGPRs behind inline asm: the compiler must never park a
+             # spilled VGPR in an AGPR of its own choosing (tests/test_isa_invariants.py checks the ISA)
+             "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
     # diagnostic builds: GPRF_BUILD_DEFS="-DGPRF_PROFILE" compiles the in-kernel cycle stamps in
-    cmd[1:1] = os.environ.get("GPRF_BUILD_DEFS", "").split()
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
+    return os.environ.get("GPRF_BUILD_DEFS", "").split() + flags
+
+
+def _build_locked(verbose):
+    """One object per source (kept under csrc/_obj next to a stamp of the flags and the headers' times: a change to the
+    host layer alone does not recompile the kernels' 90 seconds), then one link."""
+    import hashlib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = _flags()
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    tag = hashlib.sha256((" ".join(flags) + os.path.basename(LIB)).encode()).hexdigest()[:12]
+    objs = []
+    for f in SOURCES:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(objdir, "%s.%s.o" % (os.path.splitext(f)[0], tag))
+        if not (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t)):
+            cmd = [hipcc] + flags + ["-c", "-o", obj + ".tmp.%d" % os.getpid(), src]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(obj + ".tmp.%d" % os.getpid(), obj)
+            finally:
+                if os.path.exists(obj + ".tmp.%d" % os.getpid()):
+                    os.remove(obj + ".tmp.%d" % os.getpid())
+        objs.append(obj)
+    tmp = "%s.tmp.%d" % (LIB, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-pthread",
+           "-Wl,--no-undefined",      # a symbol one source file declares and the other forgot to define fails HERE
+           "-o", tmp] + objs
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, LIB)

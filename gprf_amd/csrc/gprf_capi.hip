@@ -150,6 +150,12 @@ struct gprf_ctx {
     int32_t done_seq = 0;
     bool poll_pending = false;            // the pending evaluation ends with k_done: finish_eval may poll
     bool spin = true;                     // GPRF_SYNC=block: hipStreamSynchronize instead of polling
+    // how a host-in / host-out evaluation moves its data (GPRF_IO_MODE, A/B diagnostics):
+    //   0 zero-copy: the kernels read X from, and write the result to, pinned host memory; completion = a polled word
+    //   1 copies:    X by hipMemcpyAsync H2D, result in HBM + hipMemcpyAsync D2H, hipStreamSynchronize
+    //   2 mixed:     X zero-copy in, result in HBM + hipMemcpyAsync D2H, completion = a polled word behind the copy
+    int io_mode = 0;
+    bool poisoned = false;                // an evaluation timed out: the queues may never drain — never wait for them again
 
     // the optimiser-facing form (gprf_objective): location prior N(X_obs, obs_std^2) and the log-space hyper-parameters
     bool xprior = false;
@@ -164,7 +170,14 @@ struct gprf_ctx {
     // partial vectors into slots in the front device's memory, k_sum_parts adds them into the front's pinned host vector
     std::vector<gprf_ctx *> kids;
     std::vector<double> h_Xobs_front;     // the front's copy of the prior means (gprf_objective's parts_out)
-    DevBuf<double> d_slots;
+    // the members' slots: FINE-GRAINED memory of the front device (peer stores over xGMI, coherent at system scope: a
+    // member's stores are visible to the front device's summing kernel once that member's stream event has completed) —
+    // or, when some member's device cannot reach the front device's memory, pinned host memory (every member stores
+    // over its own host link; the summing kernel reads it zero-copy): slots_on_host
+    double *slots = nullptr;              // as the devices see it
+    void *slots_base = nullptr;           // what to free
+    bool slots_on_host = false;
+    std::string slots_why;                // why the host-staged form was chosen ("" = peer stores)
     size_t slot_stride = 0;
     hipStream_t red_stream = nullptr;
     std::vector<hipEvent_t> ev_kid;
@@ -195,8 +208,16 @@ struct gprf_ctx {
 
 namespace {
 
+// why the last gprf_create / gprf_create_multi of this thread failed (there is no context to carry the text then):
+// gprf_last_error(NULL) returns it
+thread_local std::string g_create_err;
+
 int fail(gprf_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
+    return code;
+}
+int create_fail(int code, const std::string &msg) {
+    g_create_err = msg;
     return code;
 }
 
@@ -601,10 +622,15 @@ int enqueue_partition(gprf_ctx *c, const double *d_X, hipStream_t s) {
 
 // enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug); reblock: first
 // re-partition the points on the device (update_X's block_fn, gprf.py:171-172)
+// host_io: 0 = d_X / d_out are the caller's device buffers; 1 = the zero-copy host-in / host-out form (d_X / d_out are the
+// pinned host buffers as the device sees them, completion by k_done's polled word); 2 = host-in / host-out through HBM:
+// d_out = the context's device vector, copied down (with the result words) behind the kernels — polled (io_mode 2) or
+// stream-synchronised (io_mode 1) by finish_eval
 int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, double *d_out, hipStream_t s,
-                 int stop_after, bool reblock, bool host_io = false) {
+                 int stop_after, bool reblock, int host_io = 0) {
     int rc = prepare(c, s);
     if (rc != GPRF_OK) return rc;
+    c->gxu_pending = false;      // (whatever the last evaluation left to be finalized on demand is overwritten from here on)
     bool tm = c->timing;
     if (tm && !c->ev_valid) {
         for (int r = 0; r < gprf_ctx::RING; ++r)
@@ -644,7 +670,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     // the result words are mirrored into pinned memory by the assembly kernel: no copy command in the evaluation
     AssembleTab at{c->d_assign.p, c->d_posb.p, c->d_bu_ptr.p, c->d_bu_ent.p, c->d_offj.p, res_ctl(c),
                    c->d_pe.p, c->d_ebase.p, c->d_einfo.p, 0, c->d_ewgt.p,
-                   c->d_res.p, host_io ? c->h_res.d : nullptr, (int)c->res_words};
+                   c->d_res.p, host_io == 1 ? c->h_res.d : nullptr, (int)c->res_words};
     bool do_grad = stop_after >= 4 && (want_gx || want_gc);
     bool fold_gx = false;
     if (fused_build) launch_build_scatter(make_build(c), d_X, c->dx, c->dist_id, force, c->epoch, s);
@@ -693,7 +719,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     }
     // control words, unit status, block sizes -> pinned host: one download (or the assembly kernel's mirror)
     c->poll_pending = false;
-    const bool poll = host_io && stop_after >= 5 && c->spin && c->h_done.p;
+    const bool poll = host_io && stop_after >= 5 && c->spin && c->h_done.p && !(host_io == 2 && c->io_mode == 1);
     if (poll) c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
     if (stop_after >= 5) launch_assemble(ut, pl, at, kp, c->n, want_gx, want_gc, d_out, (do_grad && !fold_gx) ? 1 : 0, ob, s);
     mark();
@@ -701,11 +727,20 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         const double nel = (double)c->n * c->dx;
         const double xp_const = -0.5 * nel * std::log(2.0 * M_PI * (c->obs_std * c->obs_std));
         size_t nout = 1 + (size_t)c->n * c->dx + c->ncov + 2;
-        launch_finish(d_out, ob, (c->n + 31) / 32, xp_const, host_io ? d_out + nout : nullptr, poll ? c->h_done.d : nullptr,
-                      c->done_seq, s);
+        launch_finish(d_out, ob, (c->n + 31) / 32, xp_const, host_io ? d_out + nout : nullptr,
+                      (poll && host_io == 1) ? c->h_done.d : nullptr, c->done_seq, s);
     }
     HIP_TRY(c, hipGetLastError());
-    if (!host_io || stop_after < 5) {
+    if (host_io == 2 && stop_after >= 5) {
+        // result and result words by DMA behind the kernels; the completion word (when polled) behind the copies
+        size_t nout = 1 + (size_t)c->n * c->dx + c->ncov + 2;
+        HIP_TRY(c, hipMemcpyAsync(c->h_out.p, d_out, (nout + (objective ? 2 : 0)) * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (poll) {
+            launch_done(c->h_done.d, c->done_seq, s);
+            c->poll_pending = true;
+        }
+    } else if (!host_io || stop_after < 5) {
         HIP_TRY(c, hipMemcpyAsync(c->h_res.p, c->d_res.p, c->res_words * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     } else if (poll) {
         if (!objective) launch_done(c->h_done.d, c->done_seq, s);
@@ -767,6 +802,13 @@ int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
 // events when it recognises such an environment; this is the net under the ones it does not).  GPRF_EVAL_TIMEOUT_S
 // (default 120) bounds it.
 int bounded_stream_wait(gprf_ctx *c, hipStream_t s) {
+    if (c->poisoned) return fail(c, GPRF_ERR_HIP, "an earlier evaluation of this context timed out; the context is unusable");
+    // GPRF_SYNC=block: a true blocking wait (the host thread sleeps in the runtime) — except under a tool that may
+    // serialise the queues, where only the bounded form below can get out of a stuck evaluation
+    if (!c->spin && !potrf_tool_env()) {
+        hipError_t e = hipStreamSynchronize(s);
+        return e == hipSuccess ? GPRF_OK : fail(c, GPRF_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
     static const double limit = [] { const char *e = getenv("GPRF_EVAL_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
     auto t0 = std::chrono::steady_clock::now();
     for (long it = 0;; ++it) {
@@ -778,6 +820,9 @@ int bounded_stream_wait(gprf_ctx *c, hipStream_t s) {
             char buf[256];
             snprintf(buf, sizeof buf, "the evaluation did not finish within %.0f s (GPRF_EVAL_TIMEOUT_S): a tool that serialises "
                      "dispatches across queues? set GPRF_POTRF_DUAL=2 (one queue) or GPRF_SIDE_EVENTS=1", limit);
+            // the work is still queued (or deadlocked): nothing of this context may ever be waited for again —
+            // gprf_destroy then skips every synchronisation and leaks the buffers the device may still touch
+            c->poisoned = true;
             return fail(c, GPRF_ERR_HIP, buf);
         }
         if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 1000 : 50));
@@ -802,6 +847,9 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         c->poll_pending = false;
+    } else if (c->io_mode == 1 && !c->poisoned && !potrf_tool_env()) {
+        // the copy-based form's own completion: the runtime's stream synchronisation
+        HIP_TRY(c, hipStreamSynchronize(s));
     } else {
         int rc = bounded_stream_wait(c, s);
         if (rc != GPRF_OK) { c->eval_pending = false; return rc; }
@@ -862,14 +910,25 @@ int group_run(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll
             gprf_ctx *m = c->kids[k];
             HIP_TRY(c, hipSetDevice(m->device));
             m->objective_call = objective;
-            int rc = enqueue_eval(m, c->h_X.d, want_gx, want_gc, c->d_slots.p + (size_t)k * c->slot_stride, m->stream, 6, reblock);
+            int rc = enqueue_eval(m, c->h_X.d, want_gx, want_gc, c->slots + (size_t)k * c->slot_stride, m->stream, 6, reblock);
             m->objective_call = false;
-            if (rc != GPRF_OK) { c->err = m->err; return rc; }
+            if (rc != GPRF_OK) {
+                // the members enqueued so far still run: let them finish (bounded) so that none is left with an
+                // evaluation pending behind this error
+                c->err = m->err;
+                for (int q = 0; q < k; ++q) {
+                    gprf_ctx *mq = c->kids[q];
+                    (void)hipSetDevice(mq->device);
+                    (void)finish_eval(mq, mq->stream, nullptr, nullptr);
+                }
+                (void)hipSetDevice(c->device);
+                return rc;
+            }
             HIP_TRY(c, hipEventRecord(c->ev_kid[k], m->stream));
         }
         HIP_TRY(c, hipSetDevice(c->device));
         for (int k = 0; k < N; ++k) HIP_TRY(c, hipStreamWaitEvent(c->red_stream, c->ev_kid[k], 0));
-        launch_sum_parts(c->d_slots.p, N, c->slot_stride, nout, c->h_out.d, c->red_stream);
+        launch_sum_parts(c->slots, N, c->slot_stride, nout, c->h_out.d, c->red_stream);
         c->done_seq = c->done_seq >= 0x3fffffff ? 1 : c->done_seq + 1;
         launch_done(c->h_done.d, c->done_seq, c->red_stream);
         HIP_TRY(c, hipGetLastError());
@@ -881,7 +940,10 @@ int group_run(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *ll
                 __builtin_ia32_pause();
                 if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
                     int rc = bounded_stream_wait(c, c->red_stream);
-                    if (rc != GPRF_OK) return rc;
+                    if (rc != GPRF_OK) {
+                        for (gprf_ctx *m : c->kids) { m->poisoned = c->poisoned; m->eval_pending = false; m->poll_pending = false; }
+                        return rc;
+                    }
                     break;
                 }
             }
@@ -934,7 +996,18 @@ int run_checked(gprf_ctx *c, const double *X, int want_gx, int want_gc, double *
     int any_reblocked = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         c->objective_call = objective;
-        int rc = enqueue_eval(c, c->h_X.d, want_gx, want_gc, c->h_out.d, s, 6, reblock, true);
+        int rc;
+        if (c->io_mode == 0) {
+            rc = enqueue_eval(c, c->h_X.d, want_gx, want_gc, c->h_out.d, s, 6, reblock, 1);
+        } else {
+            // A/B forms (GPRF_IO_MODE): the result through HBM and a D2H copy; X by a copy command (1) or zero-copy (2)
+            const double *xin = c->h_X.d;
+            if (c->io_mode == 1) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_X.p, c->h_X.p, nx * sizeof(double), hipMemcpyHostToDevice, s));
+                xin = c->d_X.p;
+            }
+            rc = enqueue_eval(c, xin, want_gx, want_gc, c->d_out.p, s, 6, reblock, 2);
+        }
         c->objective_call = false;
         if (rc != GPRF_OK) return rc;
         auto tp2 = std::chrono::steady_clock::now();
@@ -980,14 +1053,25 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
                 int32_t device) {
     if (!out) return GPRF_ERR_ARG;
     *out = nullptr;
-    if (n < 0 || dy < 1 || dy > YPAD) return GPRF_ERR_ARG;
+    g_create_err.clear();
+    char why[200];
+    if (n < 0 || dy < 1 || dy > YPAD) {
+        snprintf(why, sizeof why, "n = %d, dy = %d: need n >= 0 and 1 <= dy <= %d", n, dy, YPAD);
+        return create_fail(GPRF_ERR_ARG, why);
+    }
     bool se = (dist_id == GPRF_DIST_EUCLIDEAN && kern_id == GPRF_KERN_SE);
     bool mt = (dist_id == GPRF_DIST_LLD && kern_id == GPRF_KERN_MATERN32);
-    if (!se && !mt) return GPRF_ERR_ARG;  // the two combinations the reference's callers use
-    if (se && (dx < 1 || dx > 3)) return GPRF_ERR_ARG;
-    if (mt && dx != 3) return GPRF_ERR_ARG;
+    // the two combinations the reference's callers use
+    if (!se && !mt) return create_fail(GPRF_ERR_ARG, "covariance must be (euclidean, se) or (lld, matern32)");
+    if (se && (dx < 1 || dx > 3)) return create_fail(GPRF_ERR_ARG, "(euclidean, se): 1 <= dx <= 3");
+    if (mt && dx != 3) return create_fail(GPRF_ERR_ARG, "(lld, matern32): dx must be 3 (lon, lat, depth)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return GPRF_ERR_HIP;
+    hipError_t ce = hipGetDeviceCount(&ndev);
+    if (ce != hipSuccess) return create_fail(GPRF_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(ce));
+    if (device < 0 || device >= ndev) {
+        snprintf(why, sizeof why, "device ordinal %d: this process sees %d HIP device(s)", device, ndev);
+        return create_fail(GPRF_ERR_HIP, why);
+    }
     gprf_ctx *c = new gprf_ctx();
     c->n = n; c->dx = dx; c->dy = dy; c->dist_id = dist_id; c->kern_id = kern_id; c->device = device;
     c->ndfn = se ? dx : 2;
@@ -995,13 +1079,13 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     c->n_chunks = (n + CHUNK - 1) / CHUNK;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
-        return GPRF_ERR_HIP;
+        return create_fail(GPRF_ERR_HIP, "hipSetDevice / hipStreamCreate failed");
     }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         gprf_destroy(c);
-        return GPRF_ERR_HIP;
+        return create_fail(GPRF_ERR_HIP, "could not create the side stream / its events");
     }
     {
         int can = 0;
@@ -1012,14 +1096,15 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     }
     size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
     if (c->d_X.reserve((size_t)n * dx + 1, 1.0) != hipSuccess || c->d_Y.reserve((size_t)n * dy + 1, 1.0) != hipSuccess ||
-        c->d_out.reserve(nout, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
+        c->d_out.reserve(nout + 4, 1.0) != hipSuccess || c->h_X.reserve((size_t)n * dx + 1) != hipSuccess ||
         c->h_out.reserve(nout + 4) != hipSuccess || c->h_done.reserve(16) != hipSuccess ||
         c->d_xpart.reserve((size_t)(n + 31) / 32 + 1, 1.0) != hipSuccess) {
         gprf_destroy(c);
-        return GPRF_ERR_HIP;
+        return create_fail(GPRF_ERR_HIP, "out of memory for the context's resident buffers");
     }
     c->h_done.p[0] = 0;
     if (const char *e = getenv("GPRF_SYNC")) c->spin = !(e[0] == 'b');
+    if (const char *e = getenv("GPRF_IO_MODE")) c->io_mode = (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
     *out = c;
     return GPRF_OK;
 }
@@ -1028,38 +1113,117 @@ int gprf_create_multi(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t
                       int32_t n_devices, const int32_t *devices) {
     if (!out) return GPRF_ERR_ARG;
     *out = nullptr;
-    if (n_devices < 1 || n_devices > 64 || !devices) return GPRF_ERR_ARG;
+    g_create_err.clear();
+    if (n_devices < 1 || n_devices > 64 || !devices) return create_fail(GPRF_ERR_ARG, "1 <= n_devices <= 64 device ordinals");
     gprf_ctx *c = nullptr;
     int rc = gprf_create(&c, n, dx, dy, dist_id, kern_id, devices[0]);
     if (rc != GPRF_OK) return rc;
     size_t nout = 1 + (size_t)n * dx + c->ncov + 2;
     c->slot_stride = (nout + 31) & ~(size_t)31;
-    bool ok = hipSetDevice(devices[0]) == hipSuccess && c->d_slots.reserve(c->slot_stride * n_devices + 32, 1.0) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; ok && k < n_devices; ++k) {
+    std::string why;
+    auto bail = [&](int code, const std::string &msg) {
+        gprf_destroy(c);
+        return create_fail(code, msg);
+    };
+    if (hipSetDevice(devices[0]) != hipSuccess || hipStreamCreateWithFlags(&c->red_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(GPRF_ERR_HIP, "could not create the reduction stream on the first device");
+    // Can every member's device store into the first device's memory?  If not — no peer access between two of the
+    // devices (different PCIe roots, IOMMU / container restrictions) — the slots live in pinned host memory instead:
+    // slower (every partial vector crosses a host link twice) but always available.  GPRF_GROUP_HOST_SLOTS=1 forces it
+    // (tests on one-GPU boxes).
+    bool host_slots = false;
+    if (const char *e = getenv("GPRF_GROUP_HOST_SLOTS")) {
+        if (e[0] == '1') { host_slots = true; why = "GPRF_GROUP_HOST_SLOTS=1"; }
+    }
+    for (int k = 0; k < n_devices && !host_slots; ++k) {
+        if (devices[k] == devices[0]) continue;
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, devices[k], devices[0]);
+        if (e != hipSuccess || !can) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "device %d cannot access device %d's memory (hipDeviceCanAccessPeer: %s)", devices[k], devices[0],
+                     e != hipSuccess ? hipGetErrorString(e) : "no");
+            host_slots = true;
+            why = buf;
+        }
+    }
+    (void)hipGetLastError();
+    for (int k = 0; k < n_devices; ++k) {
         gprf_ctx *m = nullptr;
-        ok = gprf_create(&m, n, dx, dy, dist_id, kern_id, devices[k]) == GPRF_OK;
-        if (!ok) break;
+        rc = gprf_create(&m, n, dx, dy, dist_id, kern_id, devices[k]);
+        if (rc != GPRF_OK) {
+            std::string msg = "member " + std::to_string(k) + ": " + g_create_err;
+            return bail(rc, msg);
+        }
         c->kids.push_back(m);
         m->rank = k;
         m->world = n_devices;
         hipEvent_t ev = nullptr;
-        ok = hipSetDevice(devices[k]) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-        if (ok) c->ev_kid.push_back(ev);
-        // the member's assembly kernel stores into the front device's memory
-        if (ok && devices[k] != devices[0]) {
-            int can = 0;
-            ok = hipDeviceCanAccessPeer(&can, devices[k], devices[0]) == hipSuccess && can;
-            if (ok) {
-                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
-                (void)hipGetLastError();
+        if (hipSetDevice(devices[k]) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return bail(GPRF_ERR_HIP, "member " + std::to_string(k) + ": could not create its completion event");
+        c->ev_kid.push_back(ev);
+        if (!host_slots && devices[k] != devices[0]) {
+            hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+            (void)hipGetLastError();
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                host_slots = true;
+                why = "hipDeviceEnablePeerAccess(" + std::to_string(devices[0]) + ") from device " + std::to_string(devices[k]) + ": " +
+                      hipGetErrorString(e);
             }
         }
     }
-    if (!ok) { gprf_destroy(c); return GPRF_ERR_HIP; }
+    if (hipSetDevice(devices[0]) != hipSuccess) return bail(GPRF_ERR_HIP, "hipSetDevice(first device)");
+    const size_t slot_bytes = (c->slot_stride * (size_t)n_devices + 32) * sizeof(double);
+    if (!host_slots) {
+        // fine-grained device memory: peer stores are coherent at system scope, the front device's loads never hit a
+        // stale cached line (coarse-grained hipMalloc memory gives no such guarantee across devices inside one process)
+        void *ptr = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&ptr, slot_bytes, hipDeviceMallocFinegrained);
+        (void)hipGetLastError();
+        if (e == hipSuccess) {
+            c->slots_base = ptr;
+            c->slots = (double *)ptr;
+        } else {
+            host_slots = true;
+            why = std::string("hipExtMallocWithFlags(fine-grained): ") + hipGetErrorString(e);
+        }
+    }
+    if (host_slots) {
+        void *hp = nullptr, *dp = nullptr;
+        hipError_t e = hipHostMalloc(&hp, slot_bytes, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, hp, 0);
+        if (e != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            return bail(GPRF_ERR_HIP, std::string("pinned host memory for the members' slots: ") + hipGetErrorString(e));
+        }
+        c->slots_base = hp;
+        c->slots = (double *)dp;
+        c->slots_on_host = true;
+        c->slots_why = why;
+    }
     *out = c;
     return GPRF_OK;
+}
+
+int gprf_group_info(const gprf_ctx *c, int32_t *n_members, int32_t *slots_on_host, int32_t cap, int32_t *devices_out,
+                    int32_t *units_out) {
+    if (!c) return GPRF_ERR_ARG;
+    const int N = (int)c->kids.size();
+    if (n_members) *n_members = N;
+    if (slots_on_host) *slots_on_host = c->slots_on_host ? 1 : 0;
+    for (int k = 0; k < N && k < cap; ++k) {
+        if (devices_out) devices_out[k] = c->kids[k]->device;
+        if (units_out) units_out[k] = c->kids[k]->static_dirty ? -1 : c->kids[k]->n_local;
+    }
+    return GPRF_OK;
+}
+
+const char *gprf_runtime_config(void) {
+    static thread_local char buf[256];
+    const char *io = getenv("GPRF_IO_MODE"), *sy = getenv("GPRF_SYNC");
+    snprintf(buf, sizeof buf, "side_mode=%d tool_env=%d potrf_dual=%d io_mode=%d sync=%s", potrf_side_mode(), potrf_tool_env() ? 1 : 0,
+             potrf_dual_enabled() ? 1 : 0, (io && (io[0] == '1' || io[0] == '2')) ? io[0] - '0' : 0, (sy && sy[0] == 'b') ? "block" : "poll");
+    return buf;
 }
 
 int gprf_destroy(gprf_ctx *c) {
@@ -1068,12 +1232,23 @@ int gprf_destroy(gprf_ctx *c) {
         fprintf(stderr, "gprf host phases over %llu evaluations (us): copy X in %.1f | enqueue %.1f | wait %.1f | copy result out %.1f\n",
                 (unsigned long long)c->host_n, c->host_us[0] / c->host_n, c->host_us[1] / c->host_n, c->host_us[2] / c->host_n,
                 c->host_us[3] / c->host_n);
-    for (gprf_ctx *k : c->kids) (void)gprf_destroy(k);
+    for (gprf_ctx *k : c->kids) {
+        if (c->poisoned) k->poisoned = true;
+        (void)gprf_destroy(k);
+    }
     c->kids.clear();
+    if (c->poisoned) {
+        // an evaluation of this context never finished (bounded_stream_wait gave up): its queues may never drain, and
+        // the device may still touch its buffers — synchronising would hang exactly where the timeout got out, freeing
+        // would pull memory from under running kernels.  Everything is leaked on purpose; the process should exit.
+        fprintf(stderr, "gprf_destroy: context poisoned by a timed-out evaluation; its streams and buffers are leaked\n");
+        delete c;
+        return GPRF_OK;
+    }
     (void)hipSetDevice(c->device);
     if (c->red_stream) { (void)hipStreamSynchronize(c->red_stream); (void)hipStreamDestroy(c->red_stream); }
     for (hipEvent_t e : c->ev_kid) (void)hipEventDestroy(e);
-    c->d_slots.release();
+    if (c->slots_base) { if (c->slots_on_host) (void)hipHostFree(c->slots_base); else (void)hipFree(c->slots_base); }
     if (c->ev_last) (void)hipEventSynchronize(c->ev_last);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_X.release(); c->d_Y.release(); c->d_out.release(); c->d_tab.release(); c->h_tab.release();
@@ -1100,7 +1275,10 @@ int gprf_destroy(gprf_ctx *c) {
     return GPRF_OK;
 }
 
-const char *gprf_last_error(const gprf_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *gprf_last_error(const gprf_ctx *c) {
+    if (c) return c->err.c_str();
+    return g_create_err.empty() ? "null context" : g_create_err.c_str();      // why this thread's last create failed
+}
 
 int gprf_set_Y(gprf_ctx *c, const double *Y) {
     if (!c || !Y) return GPRF_ERR_ARG;
@@ -1852,8 +2030,9 @@ int gprf_debug_fetch(gprf_ctx *c, int32_t l, int32_t what, double *out, int64_t 
         case 3: src = c->d_At.p + roff * YPAD; len = mp * YPAD; break;
         case 4:
             if (c->gxu_pending) {      // the evaluation folded the partials inside the assembly: the per-unit form now
-                launch_gx_finalize(make_tab(c), make_pools(c), make_kparams(c), c->gxu_want_gc, c->stream);
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                hipStream_t ls = c->last_stream ? c->last_stream : c->stream;      // (behind the evaluation, wherever it ran)
+                launch_gx_finalize(make_tab(c), make_pools(c), make_kparams(c), c->gxu_want_gc, ls);
+                HIP_TRY(c, hipStreamSynchronize(ls));
                 c->gxu_pending = false;
             }
             src = c->d_gXu.p + roff * XPAD; len = mp * XPAD; break;

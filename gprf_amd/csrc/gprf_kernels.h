@@ -189,6 +189,9 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
 int potrf_gen_maxT();
 bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
 int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
+bool potrf_run_ahead();         // the register Cholesky without workgroup barriers in its step loop (GPRF_POTRF_RA=0: with)
+int potrf_side_mode();          // how the two queues fork / join (launch_potrf): 4 = kernel-written fork word + memory-op join, 0 = events
+bool potrf_tool_env();          // a profiler / serialising launch mode is in the environment
 // The second queue for the instantiation that runs beside the main one, and how the two queues wait for each other:
 // events (11 us per dependency measured, scripts/stream_dep_latency.hip) and, for the join, a stream memory operation on a
 // device word (hipStreamWriteValue32 / hipStreamWaitValue32: 4 us) where the device supports it.  s2 = nullptr: one launch.

@@ -322,14 +322,17 @@ template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = G
 // ------------------------------------------------------------------------------------------------
 
 // ------------------------------------------------------------------------------------------------
-// K fill (gprf.py:333-343 -> VectorTree.kernel_matrix + nv I): 64x64 tile per workgroup, lane = column
-// so every wave-store is 512 contiguous bytes.  HBM-write bound: 8 mp^2 bytes per unit.
-// ------------------------------------------------------------------------------------------------
-// k_fill: the same fill by symmetry — one workgroup per 64x64 tile pair (ti <= tj): evaluates the tile once
-// (lane = column: 512-B wave stores), mirrors it through LDS and writes the transposed tile with the same
-// coalescing.  Halves the exp() work; the bytes written stay 8 mp^2 per unit.
+// K fill (gprf.py:333-343 -> VectorTree.kernel_matrix + nv I): the 64x64 blocks ti <= tj of the unit's row-major
+// mp x mp matrix (by symmetry nobody reads the others: the Cholesky wants the upper triangle, k_mgrad reads a lower
+// block's values transposed from the upper one); lane = column, so every wave-store is 512 contiguous bytes.
+// Algorithmic bytes 8 mp^2 per unit, a little over half of them written.
 // skip_T: units of at most skip_T tiles per edge are left alone (the register-resident Cholesky generates their kernel
 // matrices itself; 0 = fill every unit)
+// Round 4: one workgroup per (unit, 64-row STRIP) instead of per 64x64 block — it walks the strip's blocks tj = ti .. nt-1, so
+// the two dependent round trips at the head of a workgroup (launch-slot record, then the coordinates) are paid once per strip
+// and the launch is a single round of resident workgroups (C3 forced through the pool: 1500 strips instead of 4420 blocks);
+// SE: a thread's 16 values of a block go through exp in two groups of eight interleaved chains (exp_fast_v<8>: the same
+// arithmetic per value as exp_fast, entry for entry the bits the register Cholesky generates).
 template <int DIST, int KERN>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int skip_T) {
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
@@ -340,12 +343,9 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, 
     int mp = pad16(m);
     if ((mp >> 4) <= skip_T) return;
     int nt = (mp + 63) >> 6;
-    int pidx = blockIdx.x;
-    if (pidx >= nt * (nt + 1) / 2) return;
-    int ti = 0, rem = pidx;
-    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
-    int tj = ti + rem;
-    int r0 = ti * 64, c0 = tj * 64;
+    int ti = blockIdx.x;
+    if (ti >= nt) return;
+    int r0 = ti * 64;
     const double *Xu = pl.Xu + (size_t)ur.row_off * XS;
     int t = threadIdx.x;
 #pragma unroll
@@ -354,28 +354,75 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, 
         xr[e] = (rr < mp) ? Xu[(size_t)r0 * XS + e] : 0.0;
     }
     int cl = t & 63;
-    int col = c0 + cl;
-    double xj[XN];
-#pragma unroll
-    for (int d = 0; d < XN; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XS + d] : 0.0;
-    __syncthreads();
-    double *U = pl.K + ur.mat_off;     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
-    double diag_add = kp.nv + ut.jitter[u];
     int rbase = t >> 6;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        int rl = rbase + 4 * q;
-        int row = r0 + rl;
-        double v = 0.0;
-        if (row < mp && col < mp) {
-            if (row < m && col < m) {
-                v = KernFn<DIST, KERN>::value(kp, &xr[rl * XS], xj);
-                if (row == col) v += diag_add;
-            } else {
-                v = (row == col) ? 1.0 : 0.0;
-            }
-            U[(size_t)row * mp + col] = v;
+    double *U = pl.K + ur.mat_off;     // K pool: 64x64 blocks ti <= tj only (diagonal blocks whole)
+    double diag_add = kp.nv + ut.jitter[u];
+    // the first block's column point: asked for with the row points (one round trip), the next block's while this one computes
+    double xj[XN];
+    {
+        int col = r0 + cl;
+#pragma unroll
+        for (int d = 0; d < XN; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XS + d] : 0.0;
+    }
+    __syncthreads();
+    for (int tj = ti; tj < nt; ++tj) {
+        int col = 64 * tj + cl;
+        double xn[XN];
+        {
+            int coln = col + 64;
+#pragma unroll
+            for (int d = 0; d < XN; ++d) xn[d] = (tj + 1 < nt && coln < mp) ? Xu[(size_t)coln * XS + d] : 0.0;
         }
+        if constexpr (DIST == 0 && KERN == 0) {
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {      // (one copy of the exp code: unrolled, its scalar constants alone overflow the SGPR file)
+                double sq[8], e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int rl = rbase + 4 * (8 * h + q);
+                    double a = 0.0;
+                    for (int d = 0; d < kp.dx; ++d) {      // (KernFn<0,0>::value's loop, entry for entry)
+                        double diff = (xr[rl * XS + d] - xj[d]) * kp.inv_ls[d];
+                        a += diff * diff;
+                    }
+                    sq[q] = -a;
+                }
+                exp_fast_v<8>(sq, e);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int rl = rbase + 4 * (8 * h + q);
+                    int row = r0 + rl;
+                    if (row < mp && col < mp) {
+                        double v;
+                        if (row < m && col < m) {
+                            v = kp.sv * e[q];
+                            if (row == col) v += diag_add;
+                        } else {
+                            v = (row == col) ? 1.0 : 0.0;
+                        }
+                        U[(size_t)row * mp + col] = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                int rl = rbase + 4 * q;
+                int row = r0 + rl;
+                double v = 0.0;
+                if (row < mp && col < mp) {
+                    if (row < m && col < m) {
+                        v = KernFn<DIST, KERN>::value(kp, &xr[rl * XS], xj);
+                        if (row == col) v += diag_add;
+                    } else {
+                        v = (row == col) ? 1.0 : 0.0;
+                    }
+                    U[(size_t)row * mp + col] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < XN; ++d) xj[d] = xn[d];
     }
 }
 
@@ -535,7 +582,12 @@ __device__ __forceinline__ void ldl_pending(double (&s)[16], double wprev) {
     });
 }
 
-__device__ __forceinline__ int diag_factor16_ldl(double (&s)[16], int lr_in, double *dk, double *rdk, double *Gd) {
+// `early(d, rd, mypiv)`: called once the pivots' roots are known and BEFORE the rows are scaled into U — everything the row
+// panel's substitution needs (the rows of G in LDS, 1 / U_kk = rd) exists at that point; the run-ahead pipeline publishes
+// there and scales U off the critical chain.
+struct NoEarly { __device__ __forceinline__ void operator()(double, double, double) const {} };
+template <class Early = NoEarly>
+__device__ __forceinline__ int diag_factor16_ldl(double (&s)[16], int lr_in, double *dk, double *rdk, double *Gd, Early early = Early()) {
     double w[2] = {0.0, 0.0};
     // (LDS byte address of this lane's column of G: the rows are stored from inside the ordered sequence)
     unsigned ga = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)(Gd + lr_in);
@@ -577,6 +629,7 @@ __device__ __forceinline__ int diag_factor16_ldl(double (&s)[16], int lr_in, dou
     // the roots, all pivots at once
     double d, rd;
     sqrt_and_rsqrt(mypiv, &d, &rd);
+    early(d, rd, mypiv);
     dpp_src_ready(rd);
     static_for<0, 16>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -968,13 +1021,19 @@ constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13
 // two of them side by side nearly double the CU's throughput).  Units outside [min_T, reg_maxT] are left alone.
 // DK (GEN only): 0 = ("euclidean","se"), coordinates of XPAD doubles per point; 1 = ("lld","matern32"), the GEO_STRIDE-double
 // half-angle records (KernFn<1,1>::value per entry, k_fill<1,1>'s definition)
-template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0>
+// RA ("run-ahead", two-per-CU / eight-wave instantiations): no workgroup barrier inside the step loop — see the RA block.
+template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0, bool RA = false>
 __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &pl, int stamps, int reg_maxT, const KParams &kp,
                                                int which) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[RW];
+    // RA: the two copies of 1 / diag(U_jj) (G's second copy lives where the barrier form keeps U_jj) and
+    // the four progress words: [0] diagonal tiles factored and published, [1] rows whose first tile (j, j+1) is solved,
+    // [2] solved tiles in all (cumulative), [3] wave-steps whose trailing update is finished (cumulative)
+    __shared__ double s_rdtb[2][16];
+    __shared__ int s_flags[4];
 #ifdef GPRF_WGTRACE
     __shared__ double s_tr0;       // (WgTrace itself does not survive this kernel's register discipline)
     if (threadIdx.x == 0) s_tr0 = (double)__builtin_amdgcn_s_memrealtime();
@@ -1038,6 +1097,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     const double *Kp = pl.K + ur.mat_off;   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
     double *V = pl.V + (size_t)ur.row_off * 16;
     if (threadIdx.x == 0) s_fail = 0;
+    if (RA && threadIdx.x < 4) s_flags[threadIdx.x] = 0;
     unsigned glane = (unsigned)(lg * mp + lr);
     int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
 
@@ -1053,18 +1113,29 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // and CU-time is what the stage is short of: 140 us against 123 with the two instantiations)
     static_assert(RW == 4 || RW == 8, "RW - 1 workers + the factor wave");
     constexpr int NW = RW - 1;
+    // RA (run-ahead, round 4): wave 0's ov tiles are the FIRST ov tiles in row-major order (rows 0 and 1 of a 13-tile unit),
+    // all of them, instead of every fourth tile of the first 4 ov: what wave 0 carries besides the factor IS the step's
+    // critical chain once nobody waits at barriers (measured: with the four-way deal the run-ahead form gained nothing —
+    // a 13-tile unit's wave 0 still did a quarter of every substitution and trailing update through row 9, 12.7 k cycles
+    // per step); front-loaded, it is a heavy worker for two steps and a pure factor wave for the other ten.
     const int total = T * (T - 1) / 2;
     const int ov = total > NW * SLOTS ? total - NW * SLOTS : 0;      // (a larger share for wave 0 — total / 6 .. / 14 — measured: no change)
-    const int head = RW * ov < total ? RW * ov : total;
+    const int head = RA ? ov : (RW * ov < total ? RW * ov : total);
     const bool w0busy = ov > 0;                        // wave 0 owns tiles too
     const bool mine = wave > 0 || w0busy;
     // the tile-owning waves store a solved panel in its own step, a share each (always with one panel buffer; with two, a
     // wave 0 without tiles does it alone from the other buffer during the next substitution)
     const bool copy_now = w0busy || NPB == 1;
     const int wpos = wave == 0 ? NW : wave - 1;        // position in the RW-way deal; workers: also in the NW-way
-    const int nhead = head - wpos + NW < 0 ? 0 : (head - wpos + NW) / RW;      // this wave's tiles of the RW-way part
+    const int nhead = RA ? (wave == 0 ? ov : 0)
+                         : (head - wpos + NW < 0 ? 0 : (head - wpos + NW) / RW);      // this wave's tiles of the RW-way part
     // tiles of this wave among idx < r
     auto cnt = [&](int r) {
+        if constexpr (RA) {
+            if (wave == 0) return r < ov ? r : ov;
+            int c = r - ov - wpos + NW - 1;
+            return (r <= ov || c < 0) ? 0 : c / NW;
+        }
         if (r <= head) {
             int c = r - wpos + NW;
             return c < 0 ? 0 : c / RW;
@@ -1079,7 +1150,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     int pkv = -1, shv = 0;
     {
         int sl = lane;
-        int idx = sl < nhead ? RW * sl + wpos : (wave == 0 ? total : head + NW * (sl - nhead) + wpos);
+        int idx = RA ? (wave == 0 ? (sl < ov ? sl : total) : ov + NW * sl + wpos)
+                     : (sl < nhead ? RW * sl + wpos : (wave == 0 ? total : head + NW * (sl - nhead) + wpos));
         int i = 0, rs = 0, rl = T - 1;
         while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
         if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
@@ -1180,22 +1252,54 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             if (bad && lane == 0) s_fail = 16 * jt + bad;
         }
     };
+    // RA: the same factor, published as early as the substitution can use it — the rows of G went to LDS inside the pivot
+    // chain, 1 / diag(U_jj) is known once the roots are taken: the progress word follows at once, and the scaling of the
+    // rows into U_jj and their way to global memory happen behind it, off the chain.  G / 1 / diag in two copies by the
+    // parity of the tile.  (A failed pivot poisons everything behind it with NaN; the loop runs to its end all the same —
+    // nobody may be left waiting for a word — and the first failure is what is reported.)
+    auto factor_publish_ra = [&](int jt) {
+        __builtin_amdgcn_wave_barrier();
+        double s[16], dk, rdk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = Dt[jt * 256 + r * 16 + lr];
+        // (one base + an integer offset each: a select between two LDS pointers goes through generic pointers, and the
+        // LDS address cast inside the factor then trips the compiler — "Operand has incorrect register class")
+        double *Gb = Gd + ((jt & 1) ? -(256 + 16) : 0);      // the second copy of G lives where the barrier form keeps U_jj
+        double *rb = &s_rdtb[jt & 1][0];
+        (void)diag_factor16_ldl(s, lr, &dk, &rdk, Gb, [&](double d, double rd, double piv) {
+            unsigned long long badmask = __ballot(!(piv > 0.0)) & 0xffffull;
+            if (lane < 16) {
+                rb[lr] = rd;
+                dvals[16 * jt + lr] = d;
+                if (badmask && lane == 0 && s_fail == 0) s_fail = 16 * jt + __builtin_ctzll(badmask) + 1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) ((volatile int *)s_flags)[0] = jt + 1;
+        });
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) U[(size_t)(16 * jt + i) * mp + 16 * jt + lr] = s[i];
+        }
+    };
     // Dt[i] -= P_i^T P_i
     double *P = P0;                       // the current step's panel buffer
-    auto diag_update = [&](int i) {
+    // (pl_ / dl_: this lane's offsets lg * ldp + lr into a panel row group and lg * 16 + lr into a tile — the run-ahead loop
+    // passes copies it has made opaque inside the step, so that the addresses built from them are not kept alive across
+    // the whole loop: at the 96-register cap the compiler parked exactly those in a0 / a1, i.e. in tile slot 0)
+    auto diag_update = [&](int i, int pl_, int dl_) {
         d4 t;
         double a[4], na[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = Dt[i * 256 + 64 * q + dlane];
+        for (int q = 0; q < 4; ++q) t[q] = Dt[i * 256 + 64 * q + dl_];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            a[k] = P[(4 * k + lg) * ldp + 16 * i + lr];
+            a[k] = P[(4 * k) * ldp + 16 * i + pl_];
             na[k] = -a[k];
         }
         d4 sacc = {0.0, 0.0, 0.0, 0.0};      // (the step's 16 products from zero, then ONE addition: see "hierarchical accumulation")
         mfma4_vgpr(sacc, na, a);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dlane] = t[q] + sacc[q];
+        for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dl_] = t[q] + sacc[q];
     };
     auto load_tiles = [&]() {
         if constexpr (GEN && WPS == 2) {
@@ -1287,7 +1391,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     };
     __syncthreads();
     // wave 0 factors the first diagonal tile while the workers fetch their tiles
-    if (wave == 0) factor_publish(0);
+    if (wave == 0) {
+        if constexpr (RA) factor_publish_ra(0);
+        else factor_publish(0);
+    }
     if (mine) load_tiles();
     __syncthreads();
 
@@ -1359,6 +1466,209 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             }
         }
     };
+    // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
+    // (static walk in groups of 8 slots, like the trailing chain: the slot number must be a compile-time
+    // constant for the register numbers; a group costs one compare when none of its slots is in range)
+    auto dump_rows = [&](int s_lo, int s_hi, int lb) {
+        static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            int lo = s_lo, hi = s_hi;
+            asm volatile("" : "+s"(lo), "+s"(hi));
+            if (hi > 8 * G && lo < 8 * G + 8) {
+                static_for<0, 8>([&](auto sc) {
+                    constexpr int S = 8 * G + decltype(sc)::value;
+                    if constexpr (S < SLOTS) {
+                        int lo2 = lo, hi2 = hi;
+                        asm volatile("" : "+s"(lo2), "+s"(hi2));
+                        if (S >= lo2 && S < hi2) {
+                            int pks = PK(S);
+                            double tv[4];
+                            atile_get<S>(tv);     // stored as held (negated); the substitution's load negates
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) P[lb + (4 * q) * ldp + 16 * (pks & 31)] = tv[q];
+                        }
+                    }
+                });
+            }
+        });
+    };
+    // the trailing update of step j on this wave: the diagonal tiles beyond the look-ahead one (tile i by worker
+    // 1 + i % NW), then its live tiles, slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS
+    // panel before slot S's four MFMAs issue
+    auto trailing_update = [&](int j, int s_hi, int lb, int dl) {
+        if (wave > 0)
+            for (int i = j + 2 + (wave - 1 + NW * T - (j + 2)) % NW; i < T; i += NW) diag_update(i, lb, dl);
+        GPRF_STAMP3(1)
+        auto opnd_load = [&](int pks, double (&oa)[4], double (&ob)[4]) {
+            int pc = pks < 0 ? 0 : pks;
+            const double *Pa = P + lb + 16 * (pc >> 5);
+            const double *Pk = P + lb + 16 * (pc & 31);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                oa[t] = Pa[(4 * t) * ldp];
+                ob[t] = Pk[(4 * t) * ldp];
+            }
+        };
+        if (s_hi < s_end) {
+            // walked from the LAST slot down: the slot index stays a compile-time constant (register numbers)
+            // in straight-line code, the dead slots (below s_hi) are never visited, and one compare per tile
+            // ends the walk
+            double oa[2][4], ob[2][4];
+            d4 tt[2];      // the two temporary product tiles (slot parity)
+            tt[0] = tt[1] = d4{0.0, 0.0, 0.0, 0.0};
+            opnd_load(__builtin_amdgcn_readlane(pkv, s_end - 1), oa[0], ob[0]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { oa[1][t] = oa[0][t]; ob[1][t] = ob[0][t]; }
+            bool done = false;
+            // in groups of 8 slots, so that the slots above s_end (small units) and below s_hi (late steps)
+            // cost one compare per group instead of one per slot
+            static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
+                constexpr int G = (SLOTS + 7) / 8 - 1 - decltype(gc)::value;
+                int hi = s_hi, end = s_end;
+                asm volatile("" : "+s"(hi), "+s"(end));     // (keeps the compares from being hoisted)
+                if (!done && end > 8 * G) {
+                    static_for<0, 8>([&](auto sc) {
+                        constexpr int S = 8 * G + 7 - decltype(sc)::value;
+                        if constexpr (S < SLOTS) {
+                            int hi2 = hi, end2 = end;
+                            asm volatile("" : "+s"(hi2), "+s"(end2));
+                            if (!done && S < end2) {
+                                if (S < hi2) {
+                                    done = true;
+                                } else {
+                                    ttile_mfma_first(tt[S & 1], oa[S & 1], ob[S & 1], pkv);
+                                    if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
+                                    ttile_mfma_rest(tt[S & 1], oa[S & 1], ob[S & 1]);
+                                    // the slot before this one in the walk (S + 1, when it was live): its products have
+                                    // settled by now — into its accumulator, behind this slot's MFMAs (issued piecewise
+                                    // BETWEEN the MFMAs it was slower: 126 vs 123 us)
+                                    if constexpr (S + 1 < SLOTS) {
+                                        if (S + 1 < end2) atile_add<S + 1>(tt[(S + 1) & 1]);
+                                    }
+                                }
+                            }
+                        }
+                    });
+                }
+            });
+            // the last slot of the walk (s_hi): wait for its products, then into its accumulator
+            atile_settle();
+            static_for<0, SLOTS>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                if (S == s_hi) atile_add<S>(tt[S & 1]);
+            });
+        }
+    };
+    if constexpr (RA) {
+        // ---- the run-ahead pipeline: no workgroup barrier inside the step loop ----
+        // With barriers a step is  [all: substitution] | barrier | [wave 0: factor  ||  the others: trailing update] | barrier:
+        // the tile-owning waves idle while the next diagonal tile is factored, the factor wave idles during the substitution,
+        // and both pay the rendezvous twice.  Here every wave waits only for what IT needs, through four progress words in
+        // LDS (a wave's LDS operations are performed in order, so a word written behind the data it announces is enough):
+        //   * wave 0 needs the solved tile (j, j+1) — its owner solves it in its FIRST substitution pass and says so — to
+        //     update and factor the diagonal tile j+1; it publishes G_{j+1} (two copies of G / 1 / diag in rotation, so
+        //     that the substitution of step j may still be reading G_j) and only then scales and stores U_{j+1,j+1};
+        //   * a tile-owning wave needs G_j and the panel buffer free (every wave has finished its trailing update of step
+        //     j-1) to solve its tiles of row j, and ALL solved tiles of row j for its trailing update.
+        // The factor of tile j+1 thus runs beside the rest of step j's substitution and its trailing update instead of
+        // between two barriers.  Same arithmetic per tile in the same order as the barrier form: bit-identical factors
+        // (tests/test_gpu_variants.py; GPRF_POTRF_RA=0 restores the barrier form).  The solved panel goes to global U
+        // straight from the substitution (one store per row and lane next to the LDS store) instead of a copy pass.
+        static_assert(NPB == 1, "the run-ahead form is cut for one panel buffer");
+        volatile int *flg = s_flags;
+        // (bounded: a wave that has polled for ~0.2 s gives up and poisons the unit — reported like a failed pivot, never a
+        // hung queue; it cannot happen unless a progress word is lost)
+        auto wait_ge = [&](int idx, int target) {
+            int spins = 0;
+            while (__builtin_amdgcn_readfirstlane(flg[idx]) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 21)) {
+                    if (lane == 0) s_fail = 0x40000000 + 16 * idx;
+                    break;
+                }
+            }
+            asm volatile("" ::: "memory");
+        };
+        const int nwk = w0busy ? RW : NW;          // waves that own tiles
+        for (int j = 0; j + 1 < T; ++j) {
+            int lb = lg * ldp + lr, dl = dlane;
+            asm volatile("" : "+v"(lb));
+            asm volatile("" : "+v"(dl));
+            asm volatile("" : "+v"(pkv));
+            asm volatile("" : "+v"(shv));
+            const int s_lo = j > 0 ? __builtin_amdgcn_readlane(shv, j - 1) : 0;
+            const int s_hi = __builtin_amdgcn_readlane(shv, j);
+            if (mine) {
+                if (wave != 0) wait_ge(0, j + 1);          // G_j is published
+                wait_ge(3, nwk * j);                       // nobody reads panel j-1 any more
+                GPRF_STAMP2(0)
+                const double *Gb = Gd + ((j & 1) ? -(256 + 16) : 0);
+                const double *rb = &s_rdtb[j & 1][0];
+                dump_rows(s_lo, s_hi, lb);
+                __builtin_amdgcn_wave_barrier();
+                GPRF_STAMP2(1)
+#pragma unroll 1
+                for (int sl = s_lo + lg; __any(sl < s_hi); sl += 4) {
+                    int k = shfl_i(pkv, sl & 31) & 31;
+                    if (sl < s_hi) {
+                        unsigned col = 16 * k + lr;
+                        // byte offset of this lane's column in row 16 j of U (a unit's matrix is at most 512 KB: 32 bits);
+                        // one scalar base + one running offset instead of sixteen row pointers
+                        unsigned boff = ((unsigned)(16 * j) * (unsigned)mp + col) * 8u;
+                        double x[16];
+#pragma unroll
+                        for (int a = 0; a < 16; ++a) x[a] = -P[a * ldp + col];
+                        double uc[3] = {Gb[lr], Gb[16 + lr], 0.0};
+                        double rc[3] = {rb[0], rb[1], 0.0};
+                        static_for<0, 16>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            if (c + 2 < 16) {
+                                uc[(c + 2) % 3] = Gb[(c + 2) * 16 + lr];
+                                rc[(c + 2) % 3] = rb[c + 2];
+                            }
+                            if constexpr (c + 1 < 16) fnma_bcast16_ordered<c + 1>(x[c + 1], uc[c % 3], x[c]);
+                            double xv = x[c] * rc[c % 3];
+                            P[c * ldp + col] = xv;
+                            asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(boff), "v"(xv), "s"(U) : "memory");
+                            boff += 8u * (unsigned)mp;
+                            static_for<c + 2, 16>([&](auto ac) {
+                                constexpr int a = decltype(ac)::value;
+                                fnma_bcast16_ordered<a>(x[a], uc[c % 3], x[c]);
+                            });
+                        });
+                    }
+                    // (uniform) the first tile of row j, when this wave owns it, sits in its first slot of the row — lane row
+                    // 0 of the first pass: tile (j, j+1) is in the panel, wave 0 may go on
+                    if (sl - lg == s_lo && __builtin_amdgcn_readlane(pkv, s_lo) == 33 * j + 1) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) flg[1] = j + 1;
+                    }
+                }
+                if (s_hi > s_lo) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(&s_flags[2], s_hi - s_lo);
+                }
+                GPRF_STAMP2(2)
+            }
+            GPRF_STAMP(0)
+            if (wave == 0) {
+                wait_ge(1, j + 1);
+                GPRF_STAMP(1)
+                diag_update(j + 1, lb, dl);
+                factor_publish_ra(j + 1);
+            }
+            GPRF_STAMP(2)
+            if (mine) {
+                wait_ge(2, (j + 1) * T - ((j + 1) * (j + 2)) / 2);      // every tile of row j is solved
+                GPRF_STAMP2(3)
+                trailing_update(j, s_hi, lb, dl);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&s_flags[3], 1);
+                GPRF_STAMP2(4)
+            }
+            GPRF_STAMP(3)
+        }
+    } else
     for (int j = 0; j + 1 < T; ++j) {
         if (s_fail) break;
         // keep the per-slot tile coordinates and LDS addresses from being hoisted out of the step loop (they are
@@ -1378,30 +1688,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             if (!copy_now && j > 0) copy_panel(j - 1, 0, 1);
         }
         if (mine) {
-            // this wave's tiles of row j -> panel buffer: its slots s_lo .. s_hi-1 (slots are in row-major tile order)
-            // (static walk in groups of 8 slots, like the trailing chain: the slot number must be a compile-time
-            // constant for the register numbers; a group costs one compare when none of its slots is in range)
-            static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
-                constexpr int G = decltype(gc)::value;
-                int lo = s_lo, hi = s_hi;
-                asm volatile("" : "+s"(lo), "+s"(hi));
-                if (hi > 8 * G && lo < 8 * G + 8) {
-                    static_for<0, 8>([&](auto sc) {
-                        constexpr int S = 8 * G + decltype(sc)::value;
-                        if constexpr (S < SLOTS) {
-                            int lo2 = lo, hi2 = hi;
-                            asm volatile("" : "+s"(lo2), "+s"(hi2));
-                            if (S >= lo2 && S < hi2) {
-                                int pks = PK(S);
-                                double tv[4];
-                                atile_get<S>(tv);     // stored as held (negated); the substitution's load negates
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) P[lb + (4 * q) * ldp + 16 * (pks & 31)] = tv[q];
-                            }
-                        }
-                    });
-                }
-            });
+            dump_rows(s_lo, s_hi, lb);
             __builtin_amdgcn_wave_barrier();
             GPRF_STAMP2(0)
             // lane row lg solves the lg-th of them (a second pass only when the wave holds more than four tiles
@@ -1442,7 +1729,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         GPRF_STAMP(1)
         GPRF_STAMP2(4)
         if (wave == 0) {
-            diag_update(j + 1);
+            diag_update(j + 1, lg * ldp + lr, dlane);
             factor_publish(j + 1);
         }
         GPRF_STAMP3(3)
@@ -1452,71 +1739,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             if (w0busy) copy_panel(j, wave, RW);      // (otherwise wave 0 does it during the next substitution ...
             else if (copy_now) copy_panel(j, wave - 1, RW - 1);      // ... or, single-buffered, the three workers now)
             GPRF_STAMP3(0)
-            // diagonal tiles beyond the look-ahead one: tile i by worker 1 + i % NW
-            if (wave > 0)
-                for (int i = j + 2 + (wave - 1 + NW * T - (j + 2)) % NW; i < T; i += NW) diag_update(i);
-            GPRF_STAMP3(1)
-            // live tiles: slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS panel
-            // before slot S's four MFMAs issue
-            auto opnd_load = [&](int pks, double (&oa)[4], double (&ob)[4]) {
-                int pc = pks < 0 ? 0 : pks;
-                const double *Pa = P + lb + 16 * (pc >> 5);
-                const double *Pk = P + lb + 16 * (pc & 31);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    oa[t] = Pa[(4 * t) * ldp];
-                    ob[t] = Pk[(4 * t) * ldp];
-                }
-            };
-            if (s_hi < s_end) {
-                // walked from the LAST slot down: the slot index stays a compile-time constant (register numbers)
-                // in straight-line code, the dead slots (below s_hi) are never visited, and one compare per tile
-                // ends the walk
-                double oa[2][4], ob[2][4];
-                d4 tt[2];      // the two temporary product tiles (slot parity)
-                tt[0] = tt[1] = d4{0.0, 0.0, 0.0, 0.0};
-                opnd_load(__builtin_amdgcn_readlane(pkv, s_end - 1), oa[0], ob[0]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { oa[1][t] = oa[0][t]; ob[1][t] = ob[0][t]; }
-                bool done = false;
-                // in groups of 8 slots, so that the slots above s_end (small units) and below s_hi (late steps)
-                // cost one compare per group instead of one per slot
-                static_for<0, (SLOTS + 7) / 8>([&](auto gc) {
-                    constexpr int G = (SLOTS + 7) / 8 - 1 - decltype(gc)::value;
-                    int hi = s_hi, end = s_end;
-                    asm volatile("" : "+s"(hi), "+s"(end));     // (keeps the compares from being hoisted)
-                    if (!done && end > 8 * G) {
-                        static_for<0, 8>([&](auto sc) {
-                            constexpr int S = 8 * G + 7 - decltype(sc)::value;
-                            if constexpr (S < SLOTS) {
-                                int hi2 = hi, end2 = end;
-                                asm volatile("" : "+s"(hi2), "+s"(end2));
-                                if (!done && S < end2) {
-                                    if (S < hi2) {
-                                        done = true;
-                                    } else {
-                                        ttile_mfma_first(tt[S & 1], oa[S & 1], ob[S & 1], pkv);
-                                        if constexpr (S > 0) opnd_load(PK(S - 1), oa[(S - 1) & 1], ob[(S - 1) & 1]);
-                                        ttile_mfma_rest(tt[S & 1], oa[S & 1], ob[S & 1]);
-                                        // the slot before this one in the walk (S + 1, when it was live): its products have
-                                        // settled by now — into its accumulator, behind this slot's MFMAs (issued piecewise
-                                        // BETWEEN the MFMAs it was slower: 126 vs 123 us)
-                                        if constexpr (S + 1 < SLOTS) {
-                                            if (S + 1 < end2) atile_add<S + 1>(tt[(S + 1) & 1]);
-                                        }
-                                    }
-                                }
-                            }
-                        });
-                    }
-                });
-                // the last slot of the walk (s_hi): wait for its products, then into its accumulator
-                atile_settle();
-                static_for<0, SLOTS>([&](auto sc) {
-                    constexpr int S = decltype(sc)::value;
-                    if (S == s_hi) atile_add<S>(tt[S & 1]);
-                });
-            }
+            trailing_update(j, s_hi, lb, dlane);
         }
         GPRF_STAMP(2)
         GPRF_STAMP2(5)
@@ -1552,11 +1775,11 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
         return;
     }
-    if (wave == 0) {
+    if (!RA && wave == 0) {
         int jt = T - 1;
         for (int e = lane; e < 256; e += 64) U[(size_t)(16 * jt + (e >> 4)) * mp + 16 * jt + (e & 15)] = Ud[e];
     }
-    if (!copy_now && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
+    if (!RA && !copy_now && T >= 2) copy_panel(T - 2, wave, RW);   // the last row panel, by everyone
     __syncthreads();    // the epilogue reads U_jj back from global
     potrf_epilogue<RW>(U, V, P0, dvals, lred, mp, T, u, pl);
 #ifdef GPRF_PROFILE
@@ -1592,15 +1815,15 @@ template <int RW, int SLOTS>
 __global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg_lld(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
     potrf_reg_body<RW, SLOTS, true, 1, 1>(ut, pl, stamps, reg_maxT, kp, which);
 }
-template <int SLOTS, bool GEN>
+template <int SLOTS, bool GEN, bool RA = false>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8(UnitTab ut, Pools pl, int stamps,
                                                                                            int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<8, SLOTS, GEN, 2>(ut, pl, stamps, reg_maxT, kp, which);
+    potrf_reg_body<8, SLOTS, GEN, 2, 0, RA>(ut, pl, stamps, reg_maxT, kp, which);
 }
-template <int RW, int SLOTS, bool GEN>
+template <int RW, int SLOTS, bool GEN, bool RA = false>
 __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg2(UnitTab ut, Pools pl, int stamps,
                                                                                                 int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<RW, SLOTS, GEN, 2>(ut, pl, stamps, reg_maxT, kp, which);
+    potrf_reg_body<RW, SLOTS, GEN, 2, 0, RA>(ut, pl, stamps, reg_maxT, kp, which);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2775,7 +2998,7 @@ void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, d
 // dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
 // granted for (kernel slot, current device)
 static bool lds_needs_optin(int kernel_slot, size_t lds) {
-    static size_t granted[6][64] = {};
+    static size_t granted[10][64] = {};
     if (lds <= 48 * 1024) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
@@ -3399,7 +3622,7 @@ void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int skip_T, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0 || ut.max_T <= skip_T) return;
     int nt = (16 * ut.max_T + 63) / 64;
-    dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
+    dim3 grid(nt, ut.n_ids);      // one workgroup per (unit, 64-row strip)
     if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
     else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
 }
@@ -3441,6 +3664,65 @@ bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation 
     return on;
 }
 int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
+
+// How the two Cholesky queues wait for each other (launch_potrf): 4 = the large-unit kernel's first workgroup writes the word
+// the side queue waits for + join by stream memory operation (the product path); 0 = events both ways.
+// Any environment that may serialise dispatches across queues — a profiler or debug agent loaded into the runtime,
+// serialised / blocking launches — gets the fork and the join as EVENTS: dependencies the runtime itself resolves (slower:
+// stage 131 vs 110 us), where a stream wait on a word that a kernel of the other queue writes would never return.
+// (finish_eval bounds its wait all the same.)  GPRF_SIDE_MODE = 0..4 forces one (diagnostics).  Reported by
+// gprf_runtime_config(), so that a trace taken under a tool is labelled with the launch structure it shows.
+// the two-per-CU and the eight-wave instantiation, in the barrier form or the run-ahead form (GPRF_POTRF_RA=0: barriers)
+bool potrf_run_ahead() {
+    static const bool on = [] { const char *e = getenv("GPRF_POTRF_RA"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static void launch_reg2(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, int maxT,
+                        const KParams &kp, int which) {
+    if (potrf_run_ahead()) {
+        if (lds_needs_optin(6, lds))
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true, true>), grid, dim3(POTRF_REG_WAVES * 64), lds, s,
+                           ut, p, stamps, maxT, kp, which);
+    } else {
+        if (lds_needs_optin(3, lds))
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), grid, dim3(POTRF_REG_WAVES * 64), lds, s, ut,
+                           p, stamps, maxT, kp, which);
+    }
+}
+static void launch_reg8(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, int maxT,
+                        const KParams &kp, int which) {
+    if (potrf_run_ahead()) {
+        if (lds_needs_optin(7, lds))
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, true, true>), grid, dim3(512), lds, s, ut, p, stamps, maxT, kp, which);
+    } else {
+        if (lds_needs_optin(4, lds))
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, true>), grid, dim3(512), lds, s, ut, p, stamps, maxT, kp, which);
+    }
+}
+
+bool potrf_tool_env() {
+    static const bool tool_env = [] {
+        for (const char *v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "AMD_SERIALIZE_KERNEL",
+                              "HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION", "GPRF_SIDE_EVENTS"}) {
+            const char *e = getenv(v);
+            if (e && e[0] && !(e[0] == '0' && e[1] == 0)) return true;
+        }
+        return false;
+    }();
+    return tool_env;
+}
+int potrf_side_mode() {
+    static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : (potrf_tool_env() ? 0 : 4); }();
+    return side_mode;
+}
 
 void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side) {
     if (ut.n_ids == 0) return;
@@ -3487,27 +3769,13 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 return (e && e[0] == '2') || (c && c[0] && c[0] != '0' && c[0] != 'F' && c[0] != 'f');
             }();
             if (serial) s2 = s;      // the two instantiations one after the other on the main queue
-            // Any OTHER environment that may serialise dispatches across queues — a profiler or debug agent loaded into the
-            // runtime, serialised / blocking launches — gets the fork and the join as EVENTS: dependencies the runtime itself
-            // resolves (slower: stage 131 vs 110 us), where a stream wait on a word that a kernel of the other queue
-            // writes would never return.  (finish_eval bounds its wait all the same.)
-            static const bool tool_env = [] {
-                for (const char *v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "AMD_SERIALIZE_KERNEL",
-                                      "HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION", "GPRF_SIDE_EVENTS"}) {
-                    const char *e = getenv(v);
-                    if (e && e[0] && !(e[0] == '0' && e[1] == 0)) return true;
-                }
-                return false;
-            }();
+            // (any OTHER environment that may serialise dispatches across queues: events, see potrf_side_mode)
             const bool dual = potrf_dual_enabled();
             if (dual && s2 && ut.max_T > POTRF_SMALL_MAXT) {
                 // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
                 // larger ones one to a CU; each skips the other's units
                 int capS = POTRF_SMALL_MAXT;
                 size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
-                if (lds_needs_optin(3, ldsS))
-                    (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
                 if (lds_needs_optin(2, lds))
                     (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3518,7 +3786,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // 4 (default): no fork command — the large-unit kernel's first workgroup writes the word the side queue
                 // waits for — + join by memory operation: stage 110 (the event fork costs 12 us, all of it in front of the
                 // small-unit kernel, which finishes last)
-                static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : (tool_env ? 0 : 4); }();
+                const int side_mode = potrf_side_mode();
                 const bool fork_values = side.words && (side_mode == 1 || side_mode == 2);
                 const bool join_values = side.words && (side_mode == 1 || side_mode == 3 || side_mode == 4);
                 // mode 4: no fork command at all — the large-unit kernel's first workgroup writes the word the side queue
@@ -3543,11 +3811,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 static const bool big8 = [] { const char *e = getenv("GPRF_POTRF_BIG8"); return !(e && e[0] == '0'); }();
                 if (ut.grid_big > 0 && big8) {
                     size_t lds8 = (size_t)(16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
-                    if (lds_needs_optin(4, lds8))
-                        (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-                    hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, true>), dim3(ut.grid_big), dim3(512), lds8, s, utb, p, stamps,
-                                       reg_maxT, kp, 1);
+                    launch_reg8(dim3(ut.grid_big), lds8, s, utb, p, stamps, reg_maxT, kp, 1);
                 } else if (ut.grid_big > 0)
                     hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
                                        dim3(POTRF_REG_WAVES * 64), lds, s, utb, p, stamps, reg_maxT, kp, 1);
@@ -3560,9 +3824,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                     // back to back hang).  Every wait in this file depends on something submitted earlier.
                     (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
                 }
-                if (ut.grid_small > 0)
-                    hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.grid_small),
-                                       dim3(POTRF_REG_WAVES * 64), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
+                if (ut.grid_small > 0) launch_reg2(dim3(ut.grid_small), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
                 if (s2 != s) {      // join
                     if (join_values) {
                         (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);
@@ -3577,11 +3839,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
             }
             if (ut.max_T <= POTRF_SMALL_MAXT && dual) {
                 size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
-                if (lds_needs_optin(3, ldsS))
-                    (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS);
-                hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), dim3(ut.n_ids),
-                                   dim3(POTRF_REG_WAVES * 64), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
+                launch_reg2(dim3(ut.n_ids), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
                 return;      // (every unit has at most 13 tiles here)
             }
             if (lds_needs_optin(2, lds))

@@ -106,7 +106,16 @@ class Objective(object):
 
     def __init__(self, gprf, X0, C0, sdata, maxsec=None, log_dir=None, checkpoint=False, parallel=False):
         self.gprf, self.sdata, self.maxsec = gprf, sdata, maxsec
-        ntheta = 2 + np.shape(sdata.X_obs)[1]
+        # theta = [noise_var, signal_var, dfn_params...]: the MODEL says how many (euclidean: one lengthscale per input
+        # dimension; lld: two, whatever dx — gprf.py:578 against :278); a foreign model with the
+        # reference's surface is asked for its dfn_params, the synthetic drivers' 2 + dx is the last resort
+        ctx = getattr(gprf, "_ctx", None)
+        if ctx is not None and hasattr(ctx, "ncov"):
+            ntheta = int(ctx.ncov)
+        elif hasattr(getattr(gprf, "cov", None), "dfn_params"):
+            ntheta = 2 + len(np.ravel(gprf.cov.dfn_params))
+        else:
+            ntheta = 2 + np.shape(sdata.X_obs)[1]
         self.layout = VectorLayout(X0, C0, sdata.noise_var, ntheta)
         self.log = RunLog(log_dir, checkpoint)
         self.parts = None                   # (GPRF terms, location prior, hyper prior) of the last call

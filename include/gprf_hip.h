@@ -64,10 +64,20 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
  * one download, one synchronisation, no inter-process collective.  Every setter below applies to all members; gprf_eval /
  * gprf_update_eval / gprf_objective evaluate over the group (the location prior is added by member 0 alone); the
  * *_device forms, gprf_set_shard and the debug hooks are refused (GPRF_ERR_STATE); timing and table-build counters
- * report member 0. */
+ * report member 0.
+ * The slots are fine-grained (system-scope coherent) memory of devices[0].  When some member's device cannot store into
+ * devices[0]'s memory (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess refuse) the group is still created: the slots
+ * then live in pinned host memory (every member stores over its own host link, the summing kernel reads them zero-copy);
+ * gprf_group_info says which form is in use.  On failure *out = NULL and gprf_last_error(NULL) has the reason. */
 int gprf_create_multi(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_id, int32_t kern_id,
                       int32_t n_devices, const int32_t *devices);
+/* A multi-device group's shape (0 members for a plain context): *slots_on_host = 1 when the partial vectors are staged in
+ * pinned host memory (no peer access); devices_out / units_out (each `cap` entries, may be NULL): every member's HIP
+ * device ordinal and how many units its shard holds (-1 before the first evaluation has dealt them). */
+int gprf_group_info(const gprf_ctx *ctx, int32_t *n_members, int32_t *slots_on_host, int32_t cap, int32_t *devices_out,
+                    int32_t *units_out);
 int gprf_destroy(gprf_ctx *ctx);
+/* The text of the context's last error; ctx = NULL: why this thread's last gprf_create / gprf_create_multi failed. */
 const char *gprf_last_error(const gprf_ctx *ctx);
 
 /* self.Y (gprf.py:97): n x dy, uploaded once and kept resident in HBM. */
@@ -239,6 +249,12 @@ int gprf_table_builds(gprf_ctx *ctx, int32_t *builds);
  * work inside the kernels): "" for the product build — tests assert that, so that no measured number comes from a
  * diagnostic variant.  Space-separated names otherwise. */
 const char *gprf_build_flags(void);
+/* Launch structure the library runs with in THIS process environment, as "key=value ..." : side_mode (how the two
+ * Cholesky queues fork / join: 4 = kernel-written word + stream memory operation, the product path; 0 = events, chosen
+ * whenever a profiler or a serialising launch mode is in the environment — a trace taken under such a tool shows THAT
+ * structure), tool_env, potrf_dual, io_mode (GPRF_IO_MODE: 0 zero-copy host I/O + polled completion word, 1 copy
+ * commands + stream synchronisation, 2 zero-copy in / copy out + polled word), sync (GPRF_SYNC). */
+const char *gprf_runtime_config(void);
 
 /* HIP-event timing of the kernels, recorded on the stream the evaluation is enqueued on.
  * Stages: "gather","fill","potrf","solve","at","grad","assemble".  gprf_set_timing(ctx, 1) turns recording

@@ -48,3 +48,35 @@ def test_single_process_multi_device_bench_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "ONE process" in d["config"]["parallelism"]
     assert d["roofline"]["worst"]["kernel"].startswith("k_") and 0 < d["roofline"]["worst"]["frac"] < 1
+
+
+def test_plain_python_bench_gpus_2_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher — how a scaling driver that knows only the N = 1 command line would
+    call it: bench.py starts the two-rank job itself as a child process (before touching the GPU), relays rank 0's line,
+    adds the single-process figure from a second child, exits 0."""
+    env = dict(os.environ, GPRF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--reps", "3",
+           "--ntrain", "2000", "--nblocks", "16", "--yd", "8", "--no-c4", "--no-c5", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 2 and d["value"] > 0
+    assert "torch.distributed.run" in d["launched_by"]
+    # the record says who took part: gloo here (two ranks time-sharing one GPU), so no RCCL ranks are claimed
+    assert d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0 and d["devices_seen"] >= 1
+    assert len(d["shard_units"]) == 2 and sum(d["shard_units"]) == 16 + len_pairs(16)
+    assert d["repetitions"] == 3 and len(d["ms_per_step_samples"]) == 3
+    assert abs(d["ms_per_step"] - sorted(d["ms_per_step_samples"])[1]) < 1e-4          # the median repetition
+    sp = d["single_process"]
+    assert sp["value"] and sp["value"] == d["single_process_evals_per_s"] and "ONE process" in sp["parallelism"]
+    assert sp["group"]["members"] == 2
+
+
+def len_pairs(nblocks):
+    """pairs of the 8-neighbourhood on the g x g grid of block centres"""
+    g = int(round(nblocks ** 0.5))
+    return 2 * g * (g - 1) + 2 * (g - 1) * (g - 1)

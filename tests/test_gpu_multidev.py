@@ -107,3 +107,57 @@ def test_group_not_pd_and_too_big_units_are_reported_once():
             g._ctx.set_shard(0, 2)
         finally:
             g.close()
+
+
+def test_host_staged_slots_give_the_same_bits(monkeypatch):
+    """No peer access between two devices -> the members' partial vectors meet in pinned host memory instead of the first
+    device's memory (forced here: one GPU).  Same sums in the same order: the same bits as the peer-store form."""
+    from gprf_amd.gprf import GPRF
+    X, Y, b, cov = _case(n=2000, nb=16)
+    nbrs = b.neighbors()
+    peer = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs, devices=[0, 0])
+    a = peer.llgrad(grad_X=True, grad_cov=True)
+    nm, on_host, devs, units = peer._ctx.group_info()
+    assert nm == 2 and not on_host and devs == [0, 0] and sum(units) == peer._ctx.num_units()[0]
+    monkeypatch.setenv("GPRF_GROUP_HOST_SLOTS", "1")
+    host = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs, devices=[0, 0])
+    monkeypatch.delenv("GPRF_GROUP_HOST_SLOTS")
+    c = host.llgrad(grad_X=True, grad_cov=True)
+    assert host._ctx.group_info()[1] is True
+    assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+    rng = np.random.RandomState(4)
+    Xk = X + 0.01 * rng.randn(*X.shape)
+    peer.update_X(Xk); host.update_X(Xk)
+    a, c = peer.llgrad(grad_X=True), host.llgrad(grad_X=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1])
+    peer.close(); host.close()
+
+
+def test_group_over_distinct_devices_when_the_box_has_them():
+    """The xGMI hop itself: members on DIFFERENT physical GPUs (skipped on one-GPU boxes — the hop has never run there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from gprf_amd.gprf import GPRF
+    X, Y, b, cov = _case()
+    nbrs = b.neighbors()
+    one = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs)
+    grp = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs, devices=[0, 1])
+    rng = np.random.RandomState(2)
+    Xk = X
+    for _ in range(20):      # repeated evaluations: a stale slot from the evaluation before would show
+        Xk = Xk + 0.005 * rng.randn(*X.shape)
+        one.update_X(Xk); grp.update_X(Xk)
+        a, c = one.llgrad(grad_X=True, grad_cov=True), grp.llgrad(grad_X=True, grad_cov=True)
+        assert np.isclose(a[0], c[0], rtol=1e-12) and np.allclose(a[1], c[1], rtol=0, atol=1e-11 * np.abs(a[1]).max())
+        assert np.allclose(a[2], c[2], rtol=1e-10)
+    assert grp._ctx.group_info()[2] == [0, 1]
+    one.close(); grp.close()
+
+
+def test_create_failures_say_why():
+    from gprf_amd import _capi
+    with pytest.raises(_capi.GprfHipError, match="sees .* HIP device"):
+        _capi.Context(100, 2, 3, 0, 0, devices=[0, 4096])
+    with pytest.raises(_capi.GprfHipError, match="dx must be 3"):
+        _capi.Context(100, 2, 3, 1, 1, device=0)

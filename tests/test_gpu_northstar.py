@@ -2,8 +2,12 @@
 lscale=0.06, obs_std=0.02, with and without the 342 neighbour pairs.  Checks
   * the objective against the reference's PUBLISHED values (step 0 incl. x_prior; true-X) to the printed
     2 decimals — golden numbers from gprf_results.tgz;
-  * objective and gradient against the oracle on identical inputs: gradient max-abs error < 1e-8
-    (the north-star tolerance), ll relative 1e-12;
+  * objective and gradient against the oracle on identical inputs.  BASELINE.json's "gradient max-abs error < 1e-8" is
+    BELOW the reference path's own rounding on this configuration (the fp64 LAPACK oracle is 1.0-2.1e-8 per unit, 1.05e-7
+    on the assembled 342-pair gradient, away from an 80-bit evaluation; max |gradX| ~ 2e5), so what is asserted is (i)
+    closeness to the 80-BIT TRUTH relative to the oracle's own (|GPU - true| <= 1.1 |oracle - true| assembled; per pair
+    unit: pooled maximum, mean ratio and worst ratio, 40 units) and (ii) a bound on |GPU - oracle|, two fp64 paths:
+    4e-8 (local GP) / 3e-7 (342 pairs); ll relative 1e-12; gC relative 1e-9 (DESIGN.md section 5);
   * size-independent properties: directional finite difference, Bethe sum rule.
 Inputs are regenerated from seeds on the GPU box (N=10500 prior Cholesky through torch on the GPU)."""
 import numpy as np
@@ -162,8 +166,8 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
     nb = g.n_blocks
     sizes = np.array([ctx.debug_unit_shape(l)[0] for l in range(nb, nb + len(g.neighbors))])
     rng = np.random.RandomState(11)
-    pick = sorted(set([int(np.argmax(sizes)), int(np.argmin(sizes))] + rng.choice(len(sizes), 10, replace=False).tolist()))
-    assert len(pick) >= 8
+    pick = sorted(set([int(np.argmax(sizes)), int(np.argmin(sizes))] + rng.choice(len(sizes), 40, replace=False).tolist()))
+    assert len(pick) >= 40
     e_gpu, e_orc = [], []
     for q in pick:
         i, j = g.neighbors[q]

@@ -73,7 +73,9 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("one Cholesky queue", {"GPRF_POTRF_DUAL": "2"}),
                       ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"}),
                       ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"}),
-                      ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"})):
+                      ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"}),
+                      ("the Cholesky's step loop with workgroup barriers (no run-ahead)", {"GPRF_POTRF_RA": "0"}),
+                      ("barriers, one queue", {"GPRF_POTRF_RA": "0", "GPRF_POTRF_DUAL": "2"})):
         assert run_variant(tmp_path, env) == base, name
 
 
