@@ -13,7 +13,7 @@ N_STAGES = 7
 STAGE_NAMES = ("gather", "fill", "potrf", "solve", "at", "grad", "assemble")   # grad = k_mgrad + k_gx_finalize
 DIST_IDS = {"euclidean": 0, "lld": 1}
 KERN_IDS = {"se": 0, "matern32": 1}
-MAX_UNIT = 1024
+MAX_UNIT = 16384
 YPAD, XPAD = 64, 4
 
 _dp = ctypes.POINTER(ctypes.c_double)

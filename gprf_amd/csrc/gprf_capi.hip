@@ -144,6 +144,7 @@ struct gprf_ctx {
     int tree_nodes = 0, tree_dim = 0, tree_wrap = 0;
     int last_stop_after = 6;              // stage the last gprf_debug_run stopped after
     bool debug_mode = false;              // inside gprf_debug_run: also store the per-unit-row gradient slab (k_gx_finalize)
+    DevBuf<double> d_Vb;                  // big units: inverses of the 64 x 64 diagonal blocks (k_big_diag)
     DevBuf<double> d_K, d_U, d_W, d_V, d_Xu, d_Z, d_At, d_gXu, d_logdet, d_zzpart, d_usum, d_gcpart, d_rowpart, d_colpart, d_dbg;
     PinBuf<double> h_X, h_out;
     PinBuf<int32_t> h_done;               // [0]: sequence number of the last finished host-io evaluation (k_done)
@@ -230,6 +231,14 @@ int create_fail(int code, const std::string &msg) {
 
 inline int pad16(int m) { return (m + 15) & ~15; }
 
+// the largest unit accepted: GPRF_MAX_UNIT, or less through GPRF_MAX_UNIT_OVERRIDE (tests of the refusal path: a unit of
+// 16385 points costs 4e12 flop to get to)
+int max_unit_limit() {
+    const char *e = getenv("GPRF_MAX_UNIT_OVERRIDE");
+    int v = e ? atoi(e) : 0;
+    return (v > 0 && v < GPRF_MAX_UNIT) ? v : GPRF_MAX_UNIT;
+}
+
 int32_t *res_ctl(gprf_ctx *c) { return c->d_res.p; }
 int32_t *res_info(gprf_ctx *c) { return c->d_res.p + CTL_WORDS; }
 int32_t *res_bsize(gprf_ctx *c) { return c->d_res.p + CTL_WORDS + std::max(c->n_local, 0); }
@@ -274,6 +283,7 @@ BuildTab make_build(gprf_ctx *c) {
 
 Pools make_pools(gprf_ctx *c) {
     Pools p;
+    p.Vb = c->d_Vb.p;
     p.K = c->d_K.p; p.U = c->d_U.p; p.W = c->d_W.p; p.V = c->d_V.p; p.Xu = c->d_Xu.p; p.Y = c->d_Y.p; p.Z = c->d_Z.p;
     p.At = c->d_At.p; p.gXu = c->d_gXu.p; p.logdet = c->d_logdet.p; p.zzpart = c->d_zzpart.p; p.usum = c->d_usum.p;
     p.gcpart = c->d_gcpart.p; p.info = res_info(c); p.rowpart = c->d_rowpart.p; p.colpart = c->d_colpart.p; p.dbg = c->d_dbg.p;
@@ -336,6 +346,7 @@ int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
     HIP_TRY(c, c->d_U.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1, 1.0));
+    if (maxT > SMALL_MAX_T) HIP_TRY(c, c->d_Vb.reserve(((size_t)rows + 64 * nl1 + 64) * 64, 1.0));
     HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1, 1.0));      // XPAD, or 8 for the lld record
     HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1, 1.0));
     HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1, 1.0));
@@ -393,10 +404,10 @@ int rebuild_static(gprf_ctx *c) {
         deg[j]++;
     }
     for (int u = 0; u < nu; ++u)
-        if (um[u] > GPRF_MAX_UNIT) {
+        if (um[u] > max_unit_limit()) {
             char buf[200];
             snprintf(buf, sizeof buf, "unit %d has %d points; the kernels accept at most %d per unit (GPRF_MAX_UNIT)", u,
-                     um[u], GPRF_MAX_UNIT);
+                     um[u], max_unit_limit());
             return fail(c, GPRF_ERR_ARG, buf);
         }
     // shard: longest-processing-time-first over cost m^3 + 4 m^2 dy, on the sizes of THIS partition;
@@ -686,9 +697,13 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         side.words = c->side_values ? c->d_side.p : nullptr;
         side.seq = ++c->side_seq;
         launch_potrf(ut, pl, kp, gen, c->dist_id == 1 ? 1 : 0, s, side);
+        launch_big_potrf(ut, pl, kp, s);
     }
     mark();
-    if (stop_after >= 2) launch_solve(ut, pl, kp, s);
+    if (stop_after >= 2) {
+        launch_solve(ut, pl, kp, s);
+        launch_big_solve(ut, pl, s);
+    }
     mark();
     if (stop_after >= 3) launch_at(ut, pl, s);
     mark();
@@ -769,10 +784,10 @@ int absorb_control_words(gprf_ctx *c, bool reblocked_run, int32_t *reblocked) {
     if (ctl[CTL_OVERFLOW]) {
         int64_t mat = ((int64_t)ctl[CTL_MAT_HI] << 32) | (uint32_t)ctl[CTL_MAT_LO];
         c->need_build = true;
-        if (ctl[CTL_MAXM] > GPRF_MAX_UNIT) {
+        if (ctl[CTL_MAXM] > max_unit_limit()) {
             char buf[200];
             snprintf(buf, sizeof buf, "after re-blocking a unit has %d points; the kernels accept at most %d per unit "
-                     "(GPRF_MAX_UNIT)", ctl[CTL_MAXM], GPRF_MAX_UNIT);
+                     "(GPRF_MAX_UNIT)", ctl[CTL_MAXM], max_unit_limit());
             return fail(c, GPRF_ERR_ARG, buf);
         }
         int rc = size_workspace(c, ctl[CTL_ROWS], mat + mat / 4, ctl[CTL_MAXT]);
@@ -1258,6 +1273,7 @@ int gprf_destroy(gprf_ctx *c) {
     c->d_cs.release(); c->d_c2.release(); c->d_side.release(); c->d_Xobs.release(); c->d_xpart.release();
     c->d_tvec.release(); c->d_tcenter.release(); c->d_tsplit.release(); c->d_tleft.release(); c->d_tright.release();
     c->d_tleaf.release();
+    c->d_Vb.release();
     c->d_K.release(); c->d_U.release(); c->d_W.release(); c->d_V.release(); c->d_Xu.release();
     c->d_Z.release(); c->d_At.release(); c->d_gXu.release(); c->d_logdet.release(); c->d_zzpart.release(); c->d_usum.release();
     c->d_gcpart.release(); c->d_rowpart.release(); c->d_colpart.release(); c->d_dbg.release();

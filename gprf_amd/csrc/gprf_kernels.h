@@ -7,13 +7,14 @@
 namespace gprf {
 
 constexpr int TILE = 16;          // MFMA f64 16x16x4 tile edge
-constexpr int MAX_MP = 1024;       // largest padded unit (GPRF_MAX_UNIT)
+constexpr int MAX_MP = 16384;      // largest padded unit (GPRF_MAX_UNIT)
 constexpr int MAX_T = MAX_MP / TILE;
+constexpr int SMALL_MAX_T = 64;    // units of up to 64 tiles per edge (1024 points) run one workgroup per unit and stage; larger
+                                   // ones ("big" units) go through the blocked multi-launch path (k_big_*)
 constexpr int YPAD = 64;          // dy padded to 4 column tiles
 constexpr int XPAD = 4;           // dx padded (dx <= 3)
 constexpr int GC_SLOTS = 8;       // per-(unit, column-tile) hyper-gradient partials
 constexpr int CHUNK = 64;         // points per workgroup of the partition kernels (= per row of BuildTab::cnt)
-constexpr int MAX_TB = MAX_T / 4;   // 64-point blocks per unit edge (k_grad2's row-sum slab)
 
 // Kernel hyper-parameters, passed by value.  theta = [nv, sv, ls...] (gprf.py:160-164).
 struct KParams {
@@ -115,6 +116,7 @@ struct Pools {
     double *U;     // upper Cholesky factors (same layout; the strictly-lower part is never written)
     double *W;     // U^-T (lower triangular, row-major)
     double *V;     // inverses of U's 16x16 diagonal tiles: T tiles per unit at 16*row_off
+    double *Vb;    // big units (> 1024 points): inverses of U's 64x64 diagonal blocks, at (row_off + 64 u) * 64 (k_big_diag)
     double *Xu;    // gathered unit coordinates per padded row: XPAD doubles (euclidean) or the 8-double half-angle
                    // record of the lld distance (k_scatter_x)
     const double *Y;  // the outputs, n x dy row-major (gathered through upt where a kernel needs unit rows)
@@ -204,6 +206,9 @@ struct SideQueue {
 // dk (gen only): 0 = SE, 1 = lld / Matérn-3/2
 void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
+// units of more than 1024 points: blocked Cholesky and forward substitution over whole launches (no-ops when the launch has none)
+void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
+void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s);
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
                  bool have_K, hipStream_t s);

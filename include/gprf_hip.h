@@ -48,8 +48,10 @@ typedef struct gprf_ctx gprf_ctx;
 #define GPRF_KERN_SE 0        /* "se":       k = sv * exp(-r^2)   (no 1/2 factor) */
 #define GPRF_KERN_MATERN32 1  /* "matern32": k = sv * (1 + sqrt3 r) exp(-sqrt3 r) */
 
-/* Largest unit (block, or concatenated block pair) the kernels accept, in points. */
-#define GPRF_MAX_UNIT 1024
+/* Largest unit (block, or concatenated block pair) the kernels accept, in points.  Units of up to 1024 points run one
+ * workgroup per unit and stage; larger ones (the reference's 9-block / 1-block / 16-block runs, gprfopt_analyze.py:195,
+ * 237-238) go through a blocked multi-launch Cholesky / substitution (64 x 64 blocks) and the ordinary tiled kernels. */
+#define GPRF_MAX_UNIT 16384
 
 /* Replaces GPRF.__init__ (gprf.py:85-117) + the VectorTree construction (gprf.py:109).
  * n points, dx input dims (2 or 3), dy output columns; device = HIP device ordinal. */

@@ -17,6 +17,12 @@ RUNS = [
     "2000_2500_4_0.134164_0.044721_1.0000_50_l-bfgs-b_xcov_-1_0.0100_s0_gprf0",
     "10000_10500_100_0.060000_0.020000_1.0000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
     "10000_10500_100_0.060000_0.020000_0.1000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
+    # units of more than 1024 points (round 4): 9 blocks (unaries of ~1100 points, pairs of ~2200), 25 blocks (pairs of ~800), and
+    # the single block — the full GP on all 10000 points
+    "10000_10500_9_0.060000_0.020000_1.0000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
+    "10000_10500_9_0.060000_0.020000_0.1000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
+    "10000_10500_25_0.060000_0.020000_0.1000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
+    "10000_10500_1_0.060000_0.020000_1.0000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0",
 ]
 
 

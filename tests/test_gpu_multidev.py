@@ -69,7 +69,7 @@ def test_group_drives_the_optimiser_callback_like_one_device():
     g1.close(); g3.close()
 
 
-def test_group_not_pd_and_too_big_units_are_reported_once():
+def test_group_not_pd_and_too_big_units_are_reported_once(monkeypatch):
     from gprf_amd import GPCov, _capi, Blocker, grid_centers
     from gprf_amd.gprf import GPRF
     rng = np.random.RandomState(3)
@@ -89,6 +89,8 @@ def test_group_not_pd_and_too_big_units_are_reported_once():
     assert np.isclose(r1[0], r2[0], rtol=1e-12) and np.allclose(r1[1], r2[1], rtol=1e-9, atol=1e-9 * np.abs(r1[1]).max())
     g1.close(); g2.close()
     # a re-partition that grows a unit past GPRF_MAX_UNIT on one member: the library's message through the front context
+    # (the limit lowered to 1024 for this: a real unit of 16385 points costs 4e12 flop to get to)
+    monkeypatch.setenv("GPRF_MAX_UNIT_OVERRIDE", "1024")
     Xa = rng.rand(1200, 2)
     bl = Blocker(grid_centers(4))
     gb = GPRF(Xa, rng.randn(1200, 3), bl.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01,

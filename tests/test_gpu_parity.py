@@ -138,10 +138,13 @@ def test_not_pd_even_with_jitter_raises():
 def test_unit_too_large_is_refused():
     from gprf_amd.gprf import GPRF
     from gprf_amd import GPCov, _capi
-    X = np.random.RandomState(0).rand(1100, 2)
-    Y = np.zeros((1100, 2))
-    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), 0.01, block_idxs=[np.arange(1100)], neighbors=[])
-    with pytest.raises(_capi.GprfHipError, match="at most 1024"):
+    # refused before anything is allocated or launched (GPRF_MAX_UNIT = 16384 points; tests/test_gpu_big_units.py runs units
+    # of up to 10000)
+    n = _capi.MAX_UNIT + 1
+    X = np.random.RandomState(0).rand(n, 2)
+    Y = np.zeros((n, 2))
+    g = GPRF(X, Y, None, GPCov([1.0], [0.5, 0.5], "euclidean", "se"), 0.01, block_idxs=[np.arange(n)], neighbors=[])
+    with pytest.raises(_capi.GprfHipError, match="at most %d" % _capi.MAX_UNIT):
         g.llgrad()
     g.close()
 
