@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak (vendor data sheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): clock under load
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 STAGE_PASS_EVALS = 60     # evaluations of the separate pass that times every kernel of every evaluation
 REPS = 7                  # repetitions of the timed loop; `value` is their median (a slow leg shows in the samples, not in the headline)
 
@@ -600,6 +600,23 @@ def main():
         result["local_gp_evals_per_s"] = sequential_rate(gl, Xlist, 100, 10, grad_cov, 3)[0]
         gl.close()
     g.close()
+
+    # ---------------- the reference's coarse partitions of the SAME data (gprfopt_analyze.py:237-238): 9 blocks + 20 pairs
+    # (units of ~1100 / ~2200 points) and ONE block, the full GP on all 10000 points — units beyond one workgroup, through
+    # the blocked multi-launch path (k_big_*); gprf_results.tgz has the reference's own seconds per evaluation beside them
+    if n_members == 1 and not args.only_north_star and args.ntrain == 10000:
+        big = {}
+        for nbk, ld, tag, ref_s in ((9, 0.1, "9 blocks + 20 pairs", 85.33), (1, 1.0, "1 block (full GP)", 233.55)):
+            sd.set_centers(grid_centers(nbk))
+            gb = sd.build_gprf(local_dist=ld, device=local_rank)
+            rate, ms, smp = sequential_rate(gb, Xlist[:3], 3 if nbk == 9 else 2, 1, grad_cov, 1)
+            szb = gdist.unit_sizes(sd.block_idxs, sd.neighbors if ld < 1.0 else [])
+            big[tag] = {"evals_per_s": rate, "ms_per_eval": ms, "largest_unit_points": int(szb.max()),
+                        "algorithmic_TFLOPs": algorithmic_flops(szb, args.yd)["total"] * rate / 1e12,
+                        "reference_published_s_per_eval": ref_s}
+            gb.close()
+        sd.set_centers(grid_centers(args.nblocks))
+        result["big_units"] = big
 
     # ---------------- BASELINE configs[3] (n=80000, 841 blocks + 3192 pairs, task xcov), same sequential loop, every N
     if not args.only_north_star and not args.no_c4 and args.ntrain == 10000:

@@ -259,6 +259,7 @@ UnitTab make_tab(gprf_ctx *c) {
     t.srec = c->d_srec.p; t.big_rec = c->d_big_rec.p; t.small_rec = c->d_small_rec.p;
     t.grid_big = c->grid_big; t.grid_small = c->grid_small;
     t.fork_flag = nullptr; t.fork_seq = 0;
+    t.pm_group = 0;
     return t;
 }
 

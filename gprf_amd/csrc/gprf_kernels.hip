@@ -111,11 +111,20 @@ struct WgTrace {
 // XCD: the slot count is padded to a multiple of 8).  For launches several rounds of workgroups deep whose parts differ in
 // length: with the longest kind of part first across ALL units the launch order is longest-first by workgroup, not by unit,
 // and the tail of the launch is made of short workgroups.
-__device__ __forceinline__ bool part_major_map(int linear, int n_ids, int nparts, int *slot, int *part) {
+// G > 0 (a multiple of 8): part by part inside GROUPS of G launch slots, group after group — the parts of one unit then run
+// within about one round of workgroups of each other and find the unit's matrices still in their XCD's L2 (launch-wide, a
+// unit's parts are a whole round apart and every one fetches them again: 2.4x the algorithmic bytes in the gradient kernel)
+__device__ __forceinline__ bool part_major_map(int linear, int n_ids, int nparts, int G, int *slot, int *part) {
     int n8 = (n_ids + 7) & ~7;
-    *part = linear / n8;
-    *slot = linear - *part * n8;
-    (void)nparts;
+    if (G <= 0 || G >= n8) {
+        *part = linear / n8;
+        *slot = linear - *part * n8;
+        return *slot < n_ids;
+    }
+    int per = G * nparts;
+    int g = linear / per, rem = linear - g * per;
+    *part = rem / G;
+    *slot = g * G + (rem - *part * G);
     return *slot < n_ids;
 }
 __device__ __forceinline__ bool xcd_map(int linear, int n_ids, int nparts, int *slot, int *part) {
@@ -198,15 +207,30 @@ __device__ __forceinline__ double exp_fast(double x) {
 // treegp forms d = sqrt(r^2) with a divide per coordinate and then exp(-d*d); here the scaled differences use the
 // host-rounded reciprocal lengthscales and r^2 goes straight into exp: at most ~2 ulp apart in the exponent's
 // argument (relative 2e-16 * r^2 in k), the same size as the exp implementations' own disagreement.
+// -(r^2) with ONE order of roundings wherever an SE kernel value is made — the fill, the generation inside the register
+// Cholesky, the re-evaluation in the gradient kernel, neighbour discovery: d_i = (a_i - b_i) * (1 / l_i), d_0^2 rounded, the
+// others added fused, in order.  Written with explicit operations: under -ffp-contract=fast "d0 * d0 + d1 * d1" may fuse
+// EITHER product, and two kernels that spell the same sum differently came out 1 ulp apart in 15 % of the arguments — up to
+// 16 ulp in exp(-r^2) (round 4: k_fill_se against k_fill<0,0>, tests/diag/gpu_fill_compare.py).  Unused coordinates are 0
+// in every caller's records; three_d = false skips the third term (adding (0 - 0)^2 changes no bit).
+__device__ __forceinline__ double se_neg_r2(double a0, double a1, double a2, double b0, double b1, double b2, const double (&inv)[3],
+                                            bool three_d) {
+    double d0 = __dmul_rn(__dsub_rn(a0, b0), inv[0]);
+    double d1 = __dmul_rn(__dsub_rn(a1, b1), inv[1]);
+    double sq = __dmul_rn(d0, d0);
+    sq = __builtin_fma(d1, d1, sq);
+    if (three_d) {
+        double d2 = __dmul_rn(__dsub_rn(a2, b2), inv[2]);
+        sq = __builtin_fma(d2, d2, sq);
+    }
+    return -sq;
+}
+
 template <>
 struct KernFn<0, 0> {
+    // (xi, xj: three coordinates each, unused ones 0)
     __device__ static __forceinline__ double value(const KParams &p, const double *xi, const double *xj) {
-        double sq = 0.0;
-        for (int d = 0; d < p.dx; ++d) {
-            double diff = (xi[d] - xj[d]) * p.inv_ls[d];
-            sq += diff * diff;
-        }
-        return p.sv * exp_fast(-sq);
+        return p.sv * exp_fast(se_neg_r2(xi[0], xi[1], xi[2], xj[0], xj[1], xj[2], p.inv_ls, p.dx > 2));
     }
     // k, d k(xj, xi)/d xj[d], d k / d ls[t]
     __device__ static __forceinline__ double full(const KParams &p, const double *xi, const double *xj,
@@ -328,107 +352,9 @@ template <> struct PtRec<1> { static constexpr int STRIDE = GEO_STRIDE, NREG = G
 // Algorithmic bytes 8 mp^2 per unit, a little over half of them written.
 // skip_T: units of at most skip_T tiles per edge are left alone (the register-resident Cholesky generates their kernel
 // matrices itself; 0 = fill every unit)
-// Round 4: one workgroup per (unit, 64-row STRIP) instead of per 64x64 block — it walks the strip's blocks tj = ti .. nt-1, so
-// the two dependent round trips at the head of a workgroup (launch-slot record, then the coordinates) are paid once per strip
-// and the launch is a single round of resident workgroups (C3 forced through the pool: 1500 strips instead of 4420 blocks);
-// SE: a thread's 16 values of a block go through exp in two groups of eight interleaved chains (exp_fast_v<8>: the same
-// arithmetic per value as exp_fast, entry for entry the bits the register Cholesky generates).
+// one workgroup per 64x64 block (ti <= tj), entry by entry through KernFn<DIST, KERN>::value: the fill of the ("lld","matern32")
+// kernel, and the SE fill's reference form (GPRF_FILL_VARIANT=0; k_fill_se below is the one that runs)
 template <int DIST, int KERN>
-__global__ __launch_bounds__(256) void k_fill_strip(UnitTab ut, Pools pl, KParams kp, int skip_T) {
-    constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
-    __shared__ double xr[64 * XS];
-    const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
-    int u = ur.u;
-    int m = ur.m;
-    int mp = pad16(m);
-    if ((mp >> 4) <= skip_T) return;
-    int nt = (mp + 63) >> 6;
-    int ti = blockIdx.x;
-    if (ti >= nt) return;
-    int r0 = ti * 64;
-    const double *Xu = pl.Xu + (size_t)ur.row_off * XS;
-    int t = threadIdx.x;
-#pragma unroll
-    for (int e = t; e < 64 * XS; e += 256) {
-        int rr = r0 + e / XS;
-        xr[e] = (rr < mp) ? Xu[(size_t)r0 * XS + e] : 0.0;
-    }
-    int cl = t & 63;
-    int rbase = t >> 6;
-    double *U = pl.K + ur.mat_off;     // K pool: 64x64 blocks ti <= tj only (diagonal blocks whole)
-    double diag_add = kp.nv + ut.jitter[u];
-    // the first block's column point: asked for with the row points (one round trip), the next block's while this one computes
-    double xj[XN];
-    {
-        int col = r0 + cl;
-#pragma unroll
-        for (int d = 0; d < XN; ++d) xj[d] = (col < mp) ? Xu[(size_t)col * XS + d] : 0.0;
-    }
-    __syncthreads();
-    for (int tj = ti; tj < nt; ++tj) {
-        int col = 64 * tj + cl;
-        double xn[XN];
-        {
-            int coln = col + 64;
-#pragma unroll
-            for (int d = 0; d < XN; ++d) xn[d] = (tj + 1 < nt && coln < mp) ? Xu[(size_t)coln * XS + d] : 0.0;
-        }
-        if constexpr (DIST == 0 && KERN == 0) {
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {      // (one copy of the exp code: unrolled, its scalar constants alone overflow the SGPR file)
-                double sq[8], e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    int rl = rbase + 4 * (8 * h + q);
-                    double a = 0.0;
-                    for (int d = 0; d < kp.dx; ++d) {      // (KernFn<0,0>::value's loop, entry for entry)
-                        double diff = (xr[rl * XS + d] - xj[d]) * kp.inv_ls[d];
-                        a += diff * diff;
-                    }
-                    sq[q] = -a;
-                }
-                exp_fast_v<8>(sq, e);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    int rl = rbase + 4 * (8 * h + q);
-                    int row = r0 + rl;
-                    if (row < mp && col < mp) {
-                        double v;
-                        if (row < m && col < m) {
-                            v = kp.sv * e[q];
-                            if (row == col) v += diag_add;
-                        } else {
-                            v = (row == col) ? 1.0 : 0.0;
-                        }
-                        U[(size_t)row * mp + col] = v;
-                    }
-                }
-            }
-        } else {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                int rl = rbase + 4 * q;
-                int row = r0 + rl;
-                double v = 0.0;
-                if (row < mp && col < mp) {
-                    if (row < m && col < m) {
-                        v = KernFn<DIST, KERN>::value(kp, &xr[rl * XS], xj);
-                        if (row == col) v += diag_add;
-                    } else {
-                        v = (row == col) ? 1.0 : 0.0;
-                    }
-                    U[(size_t)row * mp + col] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < XN; ++d) xj[d] = xn[d];
-    }
-}
-
-// the fill one workgroup per 64x64 block (ti <= tj).  ILP8 (SE): a thread's 16 values go through exp in two groups of eight
-// interleaved chains instead of four at a time behind per-value branches
-template <int DIST, int KERN, bool ILP8>
 __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, int skip_T) {
     constexpr int XS = PtRec<DIST>::STRIDE, XN = PtRec<DIST>::NREG;
     __shared__ double xr[64 * XS];
@@ -460,39 +386,6 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, 
     double *U = pl.K + ur.mat_off;     // K pool: 64x64 tiles ti <= tj only (diagonal tiles whole)
     double diag_add = kp.nv + ut.jitter[u];
     int rbase = t >> 6;
-    if constexpr (ILP8 && DIST == 0 && KERN == 0) {
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            double sq[8], e[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int rl = rbase + 4 * (8 * h + q);
-                double a = 0.0;
-                for (int d = 0; d < kp.dx; ++d) {
-                    double diff = (xr[rl * XS + d] - xj[d]) * kp.inv_ls[d];
-                    a += diff * diff;
-                }
-                sq[q] = -a;
-            }
-            exp_fast_v<8>(sq, e);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int rl = rbase + 4 * (8 * h + q);
-                int row = r0 + rl;
-                if (row < mp && col < mp) {
-                    double v;
-                    if (row < m && col < m) {
-                        v = kp.sv * e[q];
-                        if (row == col) v += diag_add;
-                    } else {
-                        v = (row == col) ? 1.0 : 0.0;
-                    }
-                    U[(size_t)row * mp + col] = v;
-                }
-            }
-        }
-        return;
-    }
 #pragma unroll 4
     for (int q = 0; q < 16; ++q) {
         int rl = rbase + 4 * q;
@@ -501,11 +394,87 @@ __global__ __launch_bounds__(256) void k_fill(UnitTab ut, Pools pl, KParams kp, 
         if (row < mp && col < mp) {
             if (row < m && col < m) {
                 v = KernFn<DIST, KERN>::value(kp, &xr[rl * XS], xj);
-                if (row == col) v += diag_add;
+                if (row == col) v = __dadd_rn(v, diag_add);
             } else {
                 v = (row == col) ? 1.0 : 0.0;
             }
             U[(size_t)row * mp + col] = v;
+        }
+    }
+}
+
+// k_fill_se (round 4): the SE fill with its vector-ALU work halved.  The rocprofv3 SQ pass of k_fill<0,0> (profiles/
+// r04_fill_rocprof_summary.txt) shows what bounds it: 1.155e7 VALU wave-instructions per launch for 1.05e7 values — 70 per
+// value, 46 % of the wave cycles stalled on instruction dependencies, 24 % parked at waits, and only 84 MB written in 34 us
+// (2.4 TB/s): the vector ALU, not HBM.  Of the 70, the exponential needs 24 and the distance 6; the rest was a run-time
+// loop over the dimensions, three data-dependent branches per value and a 64-bit row * mp + col per store.  Here: blocks off
+// the diagonal (ti < tj: all their rows are inside the unit, no entry is on the diagonal) evaluate sv * exp(-r^2) with ONE
+// per-lane predicate (col < m) hoisted out; diagonal blocks select branch-free; the dimensions are unrolled (a uniform test
+// for the third), the store address is a running pointer.  Same arithmetic per entry as KernFn<0,0>::value: the same bits.
+__global__ __launch_bounds__(256) void k_fill_se(UnitTab ut, Pools pl, KParams kp, int skip_T) {
+    __shared__ double xr[64 * XPAD];
+    const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
+    int u = ur.u;
+    int m = ur.m;
+    int mp = pad16(m);
+    if ((mp >> 4) <= skip_T) return;
+    int nt = (mp + 63) >> 6;
+    int pidx = blockIdx.x;
+    if (pidx >= nt * (nt + 1) / 2) return;
+    int ti = 0, rem = pidx;
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    int tj = ti + rem;
+    int r0 = ti * 64, c0 = tj * 64;
+    const double *Xu = pl.Xu + (size_t)ur.row_off * XPAD;
+    int t = threadIdx.x;
+    {
+        int rr = r0 + (t >> 2);      // 256 threads = 64 rows x XPAD
+        xr[t] = (rr < mp) ? Xu[(size_t)r0 * XPAD + t] : 0.0;
+    }
+    int cl = t & 63;
+    int col = c0 + cl;
+    const bool two_d = kp.dx <= 2;
+    double xj0 = 0.0, xj1 = 0.0, xj2 = 0.0;
+    if (col < mp) {
+        xj0 = Xu[(size_t)col * XPAD];
+        xj1 = Xu[(size_t)col * XPAD + 1];
+        if (!two_d) xj2 = Xu[(size_t)col * XPAD + 2];
+    }
+    const double diag_add = kp.nv + ut.jitter[u];
+    __syncthreads();
+    if (col >= mp) return;
+    const int rbase = t >> 6;
+    double *dst = pl.K + ur.mat_off + (size_t)(r0 + rbase) * mp + col;      // rows r0 + rbase + 4 q: 4 mp apart
+    const size_t rstep = (size_t)4 * mp;
+    const bool colm = col < m;
+    const double sv = kp.sv;
+    const bool diag = ti == tj;
+    const int nrow = mp - r0 < 64 ? mp - r0 : 64;      // rows of this block inside the padded unit (a multiple of 16)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (16 * h >= nrow) break;      // (uniform)
+        double sq[4], e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rl = rbase + 4 * (4 * h + q);
+            sq[q] = se_neg_r2(xr[rl * XPAD], xr[rl * XPAD + 1], two_d ? 0.0 : xr[rl * XPAD + 2], xj0, xj1, xj2, kp.inv_ls, !two_d);
+        }
+        exp_fast_v<4>(sq, e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v;
+            if (!diag) {
+                v = colm ? sv * e[q] : 0.0;
+            } else {
+                const int row = r0 + rbase + 4 * (4 * h + q);
+                // (K = k(X, X) first, THEN + nv I, as the reference forms it (gprf.py:337-342): two roundings — no fused
+                // multiply-add across the two steps; k_fill<0,0> and the register Cholesky's generation do the same)
+                v = sv * e[q];
+                v = (row == col) ? __dadd_rn(v, diag_add) : v;
+                if (!(row < m && colm)) v = (row == col) ? 1.0 : 0.0;
+            }
+            *dst = v;
+            dst += rstep;
         }
     }
 }
@@ -847,7 +816,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
 
     // diagnostic stamps (GPRF_POTRF_STAMPS=1): cycles wave 0 spends in [row panel | barrier | factor | barrier]
     unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
-    bool stamp = (stamps & 7) && threadIdx.x == 0;      // (bit 3 belongs to the register kernels)
+    bool stamp = stamps && threadIdx.x == 0;
 #define GPRF_STAMP(k)                                                     \
     if (stamp) {                                                          \
         unsigned long long tn = __builtin_amdgcn_s_memtime();             \
@@ -1168,11 +1137,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     }
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lr = lane & 15, lg = lane >> 4;
-    // `wave` is a ROLE from here on (0 = the factor wave).  Which hardware wave plays it alternates with the workgroup
-    // (stamps bit 3, GPRF_POTRF_ROT=0 turns it off): the factor wave issues ~250 DPP fp64 multiply-adds per step at 16 cycles
-    // each besides its MFMAs — two co-resident workgroups whose factor waves share a SIMD leave the other three half idle
-    if ((stamps & 8) && (blockIdx.x & 1)) wave = (wave + RW / 2) & (RW - 1);
-    stamps &= 7;
+    // (round 4 measured alternating which hardware wave is the factor wave between co-resident workgroups — its ~250 DPP fp64
+    // multiply-adds per step would otherwise pile up on one SIMD: no change, 110.6 vs 109.6 us, C4 664 vs 666: they do not)
     // fixed panel pitch (an odd multiple of 16 doubles: the k-major MFMA operand reads are conflict free):
     // every LDS row offset below is an instruction immediate
     // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
@@ -1269,7 +1235,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     int row = 16 * (pk[t] >> 5) + 4 * q + lg;
-                    double v = KernFn<1, 1>::value(kp, xs + row * XS, xs + col * XS) + (row == col ? diag_add : 0.0);
+                    double v = KernFn<1, 1>::value(kp, xs + row * XS, xs + col * XS);
+                    v = (row == col) ? __dadd_rn(v, diag_add) : v;
                     if (!(row < m && col < m)) v = (row == col) ? 1.0 : 0.0;
                     out[t][q] = sign * v;
                 }
@@ -1289,17 +1256,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int row = 16 * (pk[t] >> 5) + 4 * q + lg;
-                double a = 0.0;
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    double diff = (xs[row * XPAD + d] - xj[d]) * kp.inv_ls[d];      // (unused dimensions: coordinates 0)
-                    a += diff * diff;
-                }
-                if (!two_d) {      // (uniform)
-                    double diff = (xs[row * XPAD + 2] - xj[2]) * kp.inv_ls[2];
-                    a += diff * diff;
-                }
-                sq[4 * t + q] = -a;
+                sq[4 * t + q] = se_neg_r2(xs[row * XPAD], xs[row * XPAD + 1], two_d ? 0.0 : xs[row * XPAD + 2], xj[0], xj[1], xj[2],
+                                          kp.inv_ls, !two_d);
             }
         }
         exp_fast_v<NT * 4>(sq, e);
@@ -1315,7 +1273,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     int row = 16 * (pk[t] >> 5) + 4 * q + lg;
-                    double v = kp.sv * e[4 * t + q] + (row == col ? diag_add : 0.0);
+                    double v = kp.sv * e[4 * t + q];
+                    v = (row == col) ? __dadd_rn(v, diag_add) : v;      // (two roundings, like the fill and the reference)
                     if (!(row < m && col < m)) v = (row == col) ? 1.0 : 0.0;
                     out[t][q] = sign * v;
                 }
@@ -2031,7 +1990,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 #ifdef GPRF_PROFILE
     unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (!(PM ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_) : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
+    if (!(PM ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, ut.pm_group, &slot_, &part_) : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
     // the Y workgroup (every step, a gather in front) is the longest of a unit: it is dispatched first
     part_ = part_ == 0 ? nI : part_ - 1;
     const UnitRef ur = unit_ref(ut.srec, slot_);
@@ -2441,7 +2400,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
     int slot, bp;
     WgTrace trace(ut, pl, 3);
     // (part_major: every unit's block pair 0 first, then every unit's pair 1, ...: pairs are in order of descending length)
-    if (!(part_major ? part_major_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp) : xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp))) return;
+    if (!(part_major ? part_major_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, ut.pm_group, &slot, &bp) : xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp))) return;
     const UnitRef ur = unit_ref(ut.srec, slot);
     int u = ur.u;
     int m = ur.m;
@@ -2697,15 +2656,8 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
             if constexpr (DIST == 0 && KERN == 0 && !HAVEK) {
                 double sq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        double diff = (xi[q][d] - xj[d]) * kp.inv_ls[d];
-                        a += diff * diff;
-                    }
-                    sq[q] = -a;
-                }
+                for (int q = 0; q < 4; ++q)
+                    sq[q] = se_neg_r2(xi[q][0], xi[q][1], ND > 2 ? xi[q][2] : 0.0, xj[0], xj[1], ND > 2 ? xj[2] : 0.0, kp.inv_ls, ND > 2);
                 exp_fast_v<4>(sq, Kv);                  // four chains side by side
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Kv[q] *= kp.sv;
@@ -3387,6 +3339,15 @@ static int device_cus() {
 }
 
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
+// group size of the part-major walk (part_major_map): GPRF_PM_GROUP, 0 = launch-wide
+static int pm_group() {
+    static const int g = [] { const char *e = getenv("GPRF_PM_GROUP"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) & ~7 : 0; }();
+    return g;
+}
+static int pm_grid(int n_ids, int nparts) {
+    const int G = pm_group();
+    return G > 0 ? ((n_ids + G - 1) / G) * G * nparts : xcd_grid(n_ids, nparts);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Re-blocking on the device (gprf.py:169-174: update_X re-runs block_fn before every evaluation).
@@ -3994,20 +3955,18 @@ void launch_scatter_x(const BuildTab &bt, const double *X, int dx, int dist_id, 
 void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int skip_T, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0 || ut.max_T <= skip_T) return;
     int nt = (16 * ut.max_T + 63) / 64;
-    // GPRF_FILL_VARIANT (diagnostics, A/B): 0 one workgroup per 64x64 block, four exp chains at a time; 1 one workgroup per
-    // 64-row strip walking its blocks; 2 per block with eight interleaved chains
-    static const int var = [] { const char *e = getenv("GPRF_FILL_VARIANT"); return e ? atoi(e) : 2; }();
-    const bool se = dist_id == 0 && kern_id == 0;
-    if (var == 1) {
-        dim3 grid(nt, ut.n_ids);
-        if (se) hipLaunchKernelGGL((k_fill_strip<0, 0>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-        else hipLaunchKernelGGL((k_fill_strip<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-        return;
-    }
     dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
-    if (se && var == 2) hipLaunchKernelGGL((k_fill<0, 0, true>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-    else if (se) hipLaunchKernelGGL((k_fill<0, 0, false>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-    else hipLaunchKernelGGL((k_fill<1, 1, false>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
+    // Round 4, measured on C3 forced through the pool (stage us; 117 MB algorithmic, 84 MB written): the entry-by-entry form
+    // 35.9; one workgroup per 64-row strip walking its blocks (a third of the workgroups, one round of them) 53.2; eight
+    // interleaved exp chains per thread instead of four 38.0; non-temporal stores 36.0; k_fill_se, half the vector-ALU
+    // instructions per value, 26.2 = 4.5 TB/s.  GPRF_FILL_VARIANT=0: the entry-by-entry form for the SE kernel too (A/B).
+    static const bool ref_form = [] { const char *e = getenv("GPRF_FILL_VARIANT"); return e && e[0] == '0'; }();
+    if (dist_id == 0 && kern_id == 0) {
+        if (ref_form) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
+        else hipLaunchKernelGGL(k_fill_se, grid, dim3(256), 0, s, ut, p, kp, skip_T);
+    } else {
+        hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
+    }
 }
 
 constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGPRs + 256 AGPRs each
@@ -4116,8 +4075,6 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     hipStream_t s2 = side.s2;
     const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
     int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
-    static const bool rot = [] { const char *e = getenv("GPRF_POTRF_ROT"); return !(e && e[0] == '0'); }();
-    if (rot) stamps |= 8;      // (bit 3: the register kernels alternate which hardware wave is the factor wave)
     // The register-resident kernel holds a whole CU per unit (one wave per SIMD): it wins on latency while the
     // launch is a few rounds of workgroups deep (C3: 442 units, 124 vs 145 us), the 2-workgroups-per-CU generic
     // kernel wins on throughput beyond that (C4 on one GPU: 4033 units, 857 vs 914 us).
@@ -4256,15 +4213,18 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
     static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool pm = pm_env >= 0 ? pm_env == 1 : ut.n_ids <= 2 * device_cus();
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
-        dim3 grid(xcd_grid(ut.n_ids, (ut.max_T + 3) / 4 + 1));
+        const int nparts = (ut.max_T + 3) / 4 + 1;
+        dim3 grid(pm ? pm_grid(ut.n_ids, nparts) : xcd_grid(ut.n_ids, nparts));
+        UnitTab utp = ut;
+        utp.pm_group = pm_group();
         if (ut.max_T <= 12) {
-            if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else if (ut.max_T <= 18) {      // (an exact 16-tile instantiation is slower: 82 vs 79 us, C4 674 vs 640)
-            if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else {
-            if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         }
         return;
@@ -4303,26 +4263,28 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
                  bool have_K, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     int TBm = (ut.max_T + 3) / 4;
-    dim3 grid(xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
     static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // (only while the launch is a few rounds deep: with thousands of units the ten workgroups of a unit would run far apart
     // and each fetch the unit's W / At from HBM again — C4: 809 vs 775 us)
     const int pm = pm_env >= 0 ? pm_env : (ut.n_ids <= 2 * device_cus() ? 1 : 0);
+    dim3 grid(pm ? pm_grid(ut.n_ids, TBm * (TBm + 1) / 2) : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
+    UnitTab utp = ut;
+    utp.pm_group = pm_group();
     if (dist_id == 0 && kern_id == 0) {
         // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
         int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
         if (const char *e = getenv("GPRF_MGRAD_FAST")) { if (e[0] == '0') fast = 0; }      // diagnostics: general form
         if (have_K) {
-            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
-            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, true, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, true, 0>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
         } else {
-            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, false, 1>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
-            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
-            else hipLaunchKernelGGL((k_mgrad<0, 0, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+            if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, false, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+            else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+            else hipLaunchKernelGGL((k_mgrad<0, 0, false, 0>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
         }
     } else {
-        hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, ut, p, kp, want_gc, pm);
+        hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
     }
 }
 

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4: the whole GPU suite, the rocprofv3 passes of the north-star bench, the bench itself
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+TAG=${1:-r04k}
+O=gpurun_out/$TAG
+mkdir -p $O
+timeout 2400 python3 -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1
+echo "all gpu tests rc=$?"; tail -4 $O/pytest_gpu.log
+bash scripts/profile_run.sh $TAG > $O/profile_run.log 2>&1
+tail -45 $O/profile_run.log
+cp gpurun_out/prof_$TAG/traffic.json profiles/r04_traffic.json 2>/dev/null
+timeout 1500 python3 bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
+echo "bench rc=$?"; python3 -c "
+import json;d=json.load(open('$O/bench.json'))
+print(d['value'], d['ms_per_step_samples'], d['stages_ms'], d['roofline']['worst'], d['roofline']['traffic'], d.get('c4_evals_per_s'), d.get('c5_evals_per_s'), d['roofline'].get('fill_kernel'), d.get('big_units'))"
+cp profiles/r04_traffic.json $O/ 2>/dev/null

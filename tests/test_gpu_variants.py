@@ -79,6 +79,19 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
         assert run_variant(tmp_path, env) == base, name
 
 
+def test_se_fill_forms_and_grouped_walk_agree_bit_for_bit(tmp_path):
+    """K through the pool (GPRF_FUSED_FILL=0): k_fill_se (half the vector-ALU instructions per value) against the
+    entry-by-entry k_fill<0,0>; and the solve / gradient grids walked part by part in groups of 64 launch slots against
+    launch-wide (a different launch order, the same sums)"""
+    filled = run_variant(tmp_path, {"GPRF_FUSED_FILL": "0"})
+    assert run_variant(tmp_path, {"GPRF_FUSED_FILL": "0", "GPRF_FILL_VARIANT": "0"}) == filled
+    base = run_variant(tmp_path, {})
+    assert run_variant(tmp_path, {"GPRF_PM_GROUP": "64"}) == base
+    # K generated inside the register Cholesky = K filled into the pool and read, entry for entry (both add the noise to the
+    # rounded kernel value: two roundings, as the reference does): the whole walk comes out the same
+    assert filled == base
+
+
 LLD_DRIVER = r'''
 import sys
 import numpy as np
