@@ -690,7 +690,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
-    launch_fill(c->dist_id, c->kern_id, ut, pl, kp, gen ? potrf_gen_maxT() : 0, s);
+    launch_fill(c->dist_id, c->kern_id, ut, pl, kp, gen ? potrf_gen_maxT(c->dist_id) : 0, s);
     mark();
     if (stop_after >= 1) {
         SideQueue side;

@@ -189,7 +189,7 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 // whether the register-resident Cholesky generates the kernel matrices of its units (at most potrf_gen_maxT() tiles per
 // edge) itself; larger units are filled into the K pool and factored by the generic kernel
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
-int potrf_gen_maxT();
+int potrf_gen_maxT(int dist_id);   // (20 on the SE path with its two instantiations, 16 otherwise)
 bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
 int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
 bool potrf_run_ahead();         // the register Cholesky without workgroup barriers in its step loop (GPRF_POTRF_RA=0: with)

@@ -1053,8 +1053,13 @@ __device__ __forceinline__ void mfma4_vgpr(d4 &c, const double (&a)[4], const do
                  : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
 }
 
-constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the register-resident kernel takes
+constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the four-wave register-resident kernels take
 constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
+// the eight-wave instantiation (one workgroup per CU) takes units of up to 20 tiles per edge (320 points: the seismic
+// configuration's block pairs): 8 x 20 accumulator slots hold 160 of a 20-tile unit's 190 strictly-upper tiles, the FIRST
+// 30 in row-major order (row 0 and part of row 1: they retire first and are updated at most once) wait in LDS
+constexpr int POTRF_REG8_MAXT = 20;
+constexpr int POTRF_REG8_LDP = 336;  // >= 16 * 20, = 16 mod 32
 constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13, = 16 mod 32
 // ------------------------------------------------------------------------------------------------
 // k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
@@ -1143,8 +1148,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // every LDS row offset below is an instruction immediate
     // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
     // solved panel then goes to global memory inside its own step (copy_now below), never from the other buffer
-    constexpr bool WHOLE_CU = WPS == 1 || RW == 8;     // one workgroup per CU: the wide pitch (units of up to 16 tiles)
-    constexpr int ldp = WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP;
+    constexpr bool WHOLE_CU = WPS == 1 || RW == 8;     // one workgroup per CU: the wide pitch (units of up to 16 / 20 tiles)
+    constexpr int MT = RW == 8 ? POTRF_REG8_MAXT : POTRF_REG_MAXT_C;
+    constexpr int ldp = RW == 8 ? POTRF_REG8_LDP : (WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP);
     constexpr int NPB = WPS == 1 ? 2 : 1;
     double *P0 = lds;                     // [NPB][16][ldp] row panel j of U in buffer j & (NPB - 1): a pure-factor wave 0
     double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
@@ -1152,7 +1158,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *Gd = rdt + 16;                // [16][16]  rows of G = D^-1 U_jj (unit triangular: the substitution's operand)
     double *dvals = Gd + 256;             // [16 T]    diagonal of U
-    double *Dt = dvals + 16 * POTRF_REG_MAXT_C;   // [T][16][16] diagonal tiles of the trailing matrix
+    double *Dt = dvals + 16 * MT;         // [T][16][16] diagonal tiles of the trailing matrix
     double *U = pl.U + ur.mat_off;
     const double *Kp = pl.K + ur.mat_off;   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
     double *V = pl.V + (size_t)ur.row_off * 16;
@@ -1178,7 +1184,12 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // critical chain once nobody waits at barriers (measured: with the four-way deal the run-ahead form gained nothing —
     // a 13-tile unit's wave 0 still did a quarter of every substitution and trailing update through row 9, 12.7 k cycles
     // per step); front-loaded, it is a heavy worker for two steps and a pure factor wave for the other ten.
-    const int total = T * (T - 1) / 2;
+    // n_lds: tiles beyond ALL RW * SLOTS accumulator slots (the eight-wave kernel, T = 19, 20): the first n_lds tiles in
+    // row-major order stay in LDS (Ot) — solved from there when their row comes up, updated there until then; the others
+    // (real index n_lds + idx) are dealt as before
+    const int total_all = T * (T - 1) / 2;
+    const int n_lds = (RW == 8 && total_all > RW * SLOTS) ? total_all - RW * SLOTS : 0;      // (RW == 4: a constant 0)
+    const int total = total_all - n_lds;
     const int ov = total > NW * SLOTS ? total - NW * SLOTS : 0;      // (a larger share for wave 0 — total / 6 .. / 14 — measured: no change)
     const int head = RA ? ov : (RW * ov < total ? RW * ov : total);
     const bool w0busy = ov > 0;                        // wave 0 owns tiles too
@@ -1187,7 +1198,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     const int nhead = RA ? (wave == 0 ? ov : 0)
                          : (head - wpos + NW < 0 ? 0 : (head - wpos + NW) / RW);      // this wave's tiles of the RW-way part
     // tiles of this wave among idx < r
-    auto cnt = [&](int r) {
+    auto cnt = [&](int r_all) {
+        const int r = r_all > n_lds ? r_all - n_lds : 0;      // (row boundaries come as real tile indices)
         if constexpr (RA) {
             if (wave == 0) return r < ov ? r : ov;
             int c = r - ov - wpos + NW - 1;
@@ -1210,8 +1222,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         int idx = RA ? (wave == 0 ? (sl < ov ? sl : total) : ov + NW * sl + wpos)
                      : (sl < nhead ? RW * sl + wpos : (wave == 0 ? total : head + NW * (sl - nhead) + wpos));
         int i = 0, rs = 0, rl = T - 1;
-        while (rl > 0 && idx >= rs + rl) { rs += rl; --rl; ++i; }
-        if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idx - rs);
+        const int idr = idx + n_lds;                    // the tile's real row-major index
+        while (rl > 0 && idr >= rs + rl) { rs += rl; --rl; ++i; }
+        if (mine && rl > 0 && idx < total && lane < SLOTS) pkv = 32 * i + i + 1 + (idr - rs);
         int jj = lane < T - 1 ? lane : T - 1;           // rows 0..jj end at tile index (jj+1) T - (jj+1)(jj+2)/2
         shv = mine ? cnt((jj + 1) * T - ((jj + 1) * (jj + 2)) / 2) : 0;
         if (shv > SLOTS) shv = SLOTS;
@@ -1222,6 +1235,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // diagonal); the unit's coordinates wait in LDS
     double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XS], GEN only (the launcher sizes the LDS)
     constexpr int XS = DK == 1 ? GEO_STRIDE : XPAD;
+    double *Ot = xs + (GEN ? 16 * (T < reg_maxT ? T : reg_maxT) * XS : 0);      // [n_lds][16][16] the tiles that wait in LDS
     const double diag_add = kp.nv + ut.jitter[u];
     // NT tiles (pk = 32 * tile row + tile column) side by side, branch-free: this wave is alone on its SIMD, so the
     // only thing that hides the latency of one exp()'s dependent chain is the other 4 NT - 1 evaluations
@@ -1299,6 +1313,25 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             for (int q = 0; q < 4; ++q) {
                 const double *Cs = Kp + (size_t)(16 * i + 4 * q) * mp + 16 * i;
                 Dt[i * 256 + 64 * q + dlane] = Cs[glane];
+            }
+        }
+    }
+    // the tiles that wait in LDS (n_lds > 0: units of 19, 20 tiles per edge in the eight-wave kernel), as they are (not negated)
+    for (int t = wave; t < n_lds; t += RW) {
+        int i = 0, rs = 0, rl = T - 1;
+        while (t >= rs + rl) { rs += rl; --rl; ++i; }
+        const int k = i + 1 + (t - rs);
+        if constexpr (GEN) {
+            double kv[1][4];
+            int pk[1] = {32 * i + k};
+            kgen(std::integral_constant<int, 1>{}, pk, kv, 1.0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ot[t * 256 + 64 * q + dlane] = kv[0][q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double *Cs = Kp + (size_t)(16 * i + 4 * q) * mp + 16 * k;
+                Ot[t * 256 + 64 * q + dlane] = Cs[glane];
             }
         }
     }
@@ -1470,7 +1503,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
         // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
         // (volatile) accumulator write, which nothing is moved across
-        constexpr int PRO_BATCH = 10;
+        constexpr int PRO_BATCH = WPS == 1 ? 10 : 4;      // (the 256-register instantiations: 96 VGPRs)
         static_for<0, (SLOTS + PRO_BATCH - 1) / PRO_BATCH>([&](auto bc) {
             constexpr int B0 = decltype(bc)::value * PRO_BATCH;
             double kv[PRO_BATCH][4];
@@ -1594,6 +1627,46 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             if (par) flush(pend, tt[1]);
             else flush(pend, tt[0]);
         }
+        // row j's tiles that waited in LDS (not negated: +V_jj), dealt over all the waves
+        const int rsj = j * T - (j * (j + 1)) / 2;            // first tile of row j, row-major
+        if (rsj < n_lds) {      // (uniform)
+            const int t1 = rsj + (T - 1 - j) < n_lds ? rsj + (T - 1 - j) : n_lds;
+            double vp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vp[t] = -va[t];
+            for (int t = rsj + wave; t < t1; t += RW) {
+                double b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = Ot[t * 256 + 64 * q + dl];
+                d4 r = {0.0, 0.0, 0.0, 0.0};
+                mfma4_vgpr(r, vp, b);
+                flush(j + 1 + (t - rsj), r);
+            }
+        }
+    };
+    // the trailing update of step j on the tiles that wait in LDS (rows > j), dealt over the workers
+    auto update_lds_tiles = [&](int j, int lb, int dl) {
+        const int rs1 = (j + 1) * T - ((j + 1) * (j + 2)) / 2;      // first tile of row j + 1
+        if (rs1 >= n_lds || wave == 0) return;
+        for (int t = rs1 + (wave - 1); t < n_lds; t += NW) {
+            int i = j + 1, r0_ = rs1, rl = T - 2 - j;
+            while (t >= r0_ + rl) { r0_ += rl; --rl; ++i; }
+            const int k = i + 1 + (t - r0_);
+            d4 c;
+            double a[4], na[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = Ot[t * 256 + 64 * q + dl];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = P[(4 * q) * ldp + 16 * i + lb];
+                b[q] = P[(4 * q) * ldp + 16 * k + lb];
+                na[q] = -a[q];
+            }
+            d4 sacc = {0.0, 0.0, 0.0, 0.0};
+            mfma4_vgpr(sacc, na, b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ot[t * 256 + 64 * q + dl] = c[q] + sacc[q];
+        }
     };
     // the trailing update of step j on this wave: the diagonal tiles beyond the look-ahead one (tile i by worker
     // 1 + i % NW), then its live tiles, slots s_hi .. s_end-1; the MFMA operands of slot S+1 are fetched from the LDS
@@ -1601,6 +1674,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     auto trailing_update = [&](int j, int s_hi, int lb, int dl) {
         if (wave > 0)
             for (int i = j + 2 + (wave - 1 + NW * T - (j + 2)) % NW; i < T; i += NW) diag_update(i, lb, dl);
+        if (n_lds > 0) update_lds_tiles(j, lb, dl);
         GPRF_STAMP3(1)
         auto opnd_load = [&](int pks, double (&oa)[4], double (&ob)[4]) {
             int pc = pks < 0 ? 0 : pks;
@@ -1742,8 +1816,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         if (s_fail) break;
         // keep the per-slot tile coordinates and LDS addresses from being hoisted out of the step loop (they are
         // loop invariant, and 18 slots of them would push the accumulators out of the register file)
-        int lb = lg * ldp + lr;
+        int lb = lg * ldp + lr, dl = dlane;
         asm volatile("" : "+v"(lb));
+        asm volatile("" : "+v"(dl));
         asm volatile("" : "+v"(pkv));
         // this worker's slots [s_lo, s_hi) hold tiles of row j, [s_hi, s_end) the live tiles below it
         asm volatile("" : "+v"(shv));
@@ -1755,7 +1830,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             for (int e = lane; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
         }
         if (mine) {
-            solve_rows(j, s_lo, s_hi, lb, dlane, Vd0);
+            solve_rows(j, s_lo, s_hi, lb, dl, Vd0);
             GPRF_STAMP2(2)
         }
         GPRF_STAMP(0)
@@ -1764,13 +1839,13 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         GPRF_STAMP(1)
         GPRF_STAMP2(4)
         if (wave == 0) {
-            diag_update(j + 1, lg * ldp + lr, dlane);
+            diag_update(j + 1, lb, dl);
             factor_publish(j + 1);
         }
         GPRF_STAMP3(3)
         if (mine) {
             GPRF_STAMP3(0)
-            trailing_update(j, s_hi, lb, dlane);
+            trailing_update(j, s_hi, lb, dl);
         }
         GPRF_STAMP(2)
         GPRF_STAMP2(5)
@@ -3997,7 +4072,19 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     const bool se = dist_id == 0 && kern_id == 0, lld = dist_id == 1 && kern_id == 1 && lld_gen;
     return !off && (se || lld) && ut.n_ids > 0 && potrf_use_reg(ut);
 }
-int potrf_gen_maxT() { return POTRF_REG_MAXT_C; }
+// (the eight-wave instantiation — the large-unit kernel of the two-queue SE path, and the non-generating register kernel —
+// takes units of up to POTRF_REG8_MAXT tiles per edge: 140 .. 160 tiles in accumulators, up to 30 more waiting in LDS)
+static bool potrf_big8() {
+    static const bool big8 = [] { const char *e = getenv("GPRF_POTRF_BIG8"); return !(e && e[0] == '0'); }();
+    return big8;
+}
+bool potrf_dual_enabled();
+int potrf_gen_maxT(int dist_id) { return dist_id == 0 && potrf_dual_enabled() && potrf_big8() ? POTRF_REG8_MAXT : POTRF_REG_MAXT_C; }
+// LDS of the eight-wave instantiation for units of up to capT tiles per edge (doubles)
+static size_t potrf_reg8_lds(int capT, int xs_stride) {
+    const int total = capT * (capT - 1) / 2, n_lds = total > 8 * 20 ? total - 8 * 20 : 0;
+    return (size_t)(16 * POTRF_REG8_LDP + 256 + 16 + 256 + 16 * POTRF_REG8_MAXT + 256 * capT + 16 * capT * xs_stride + 256 * n_lds);
+}
 
 constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
 constexpr int POTRF_SMALL_MAXT = 13;
@@ -4040,8 +4127,13 @@ static void launch_reg2(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut,
     }
 }
 static void launch_reg8(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, int maxT,
-                        const KParams &kp, int which) {
-    if (potrf_run_ahead()) {
+                        const KParams &kp, int which, bool gen = true) {
+    if (!gen) {
+        if (lds_needs_optin(8, lds))
+            (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, false>), grid, dim3(512), lds, s, ut, p, stamps, maxT, kp, which);
+    } else if (potrf_run_ahead()) {
         if (lds_needs_optin(7, lds))
             (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -4081,6 +4173,11 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
     bool use_reg = potrf_use_reg(ut);
     int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
+    // (the eight-wave instantiation takes units of up to 20 tiles: the non-generating path as a whole, the SE path's large-unit
+    // list)
+    const bool dual = potrf_dual_enabled();
+    const bool wide = use_reg && potrf_big8() && (gen ? (dk == 0 && dual) : true);
+    if (wide) reg_maxT = POTRF_REG8_MAXT;
     // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
     auto launch_generic = [&]() {
         if (ut.max_T <= reg_maxT) return;
@@ -4092,7 +4189,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     };
     if (reg_maxT) {
         int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
-        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT) * sizeof(double);
+        const int capT4 = capT < POTRF_REG_MAXT ? capT : POTRF_REG_MAXT;       // the four-wave instantiations' share
+        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT4) * sizeof(double);
         if (gen && dk == 1) {
             // ("lld","matern32"): one instantiation over every unit of up to 16 tiles (no size classes: the class lists are
             // built for the SE path only); larger units were filled and go to the generic kernel
@@ -4106,7 +4204,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
             return;
         }
         if (gen) {
-            lds += (size_t)(16 * capT * XPAD) * sizeof(double);     // the unit's coordinates
+            lds += (size_t)(16 * capT4 * XPAD) * sizeof(double);     // the unit's coordinates
             // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the
             // profiler then serialises the dispatches of ALL queues, and the stream-memory-operation wait that joins the two
             // queues in front of the solve would never see its value written (observed: the run hangs)
@@ -4117,8 +4215,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
             }();
             if (serial) s2 = s;      // the two instantiations one after the other on the main queue
             // (any OTHER environment that may serialise dispatches across queues: events, see potrf_side_mode)
-            const bool dual = potrf_dual_enabled();
-            if (dual && s2 && ut.max_T > POTRF_SMALL_MAXT) {
+            if (dual && !s2) s2 = s;
+            if (dual && ut.max_T > POTRF_SMALL_MAXT) {
                 // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
                 // larger ones one to a CU; each skips the other's units
                 int capS = POTRF_SMALL_MAXT;
@@ -4155,9 +4253,9 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
                 // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
                 // the grids follow the list lengths of the last synchronised partition with a little slack)
-                static const bool big8 = [] { const char *e = getenv("GPRF_POTRF_BIG8"); return !(e && e[0] == '0'); }();
+                const bool big8 = potrf_big8();
                 if (ut.grid_big > 0 && big8) {
-                    size_t lds8 = (size_t)(16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
+                    size_t lds8 = potrf_reg8_lds(capT, XPAD) * sizeof(double);
                     launch_reg8(dim3(ut.grid_big), lds8, s, utb, p, stamps, reg_maxT, kp, 1);
                 } else if (ut.grid_big > 0)
                     hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
@@ -4189,11 +4287,18 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
                 launch_reg2(dim3(ut.n_ids), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
                 return;      // (every unit has at most 13 tiles here)
             }
+            // (one instantiation: GPRF_POTRF_DUAL=0 — reg_maxT is 16 then, see wide)
             if (lds_needs_optin(2, lds))
                 (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.n_ids),
                                dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 0);
+            launch_generic();
+            return;
+        }
+        if (wide) {
+            // the K pool's units of up to 20 tiles, eight waves a unit, one launch over the launch order (longest units first)
+            launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
             launch_generic();
             return;
         }

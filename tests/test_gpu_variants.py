@@ -79,6 +79,54 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
         assert run_variant(tmp_path, env) == base, name
 
 
+WIDE_DRIVER = r'''
+import sys
+import numpy as np
+from gprf_amd import Blocker, grid_centers, GPCov
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(31)
+n = 2400
+X = rng.rand(n, 2)
+Y = rng.randn(n, 7)
+b = Blocker(grid_centers(16))
+g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.09, 0.11], "euclidean", "se"), 0.02, neighbors=b.neighbors())
+sz = [len(u) for u in g.block_idxs]
+tiles = sorted(set((sz[i] + sz[j] + 15) // 16 for i, j in g.neighbors))
+assert tiles[0] >= 17 and 19 in tiles and 20 in tiles and tiles[-1] > 20, tiles
+ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
+g.close()
+'''
+
+
+def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
+    """16 blocks of ~150 points: pairs of 17-22 tiles per edge.  The eight-wave register kernel takes those of up to 20 (160
+    tiles in accumulators, up to 30 waiting in LDS), generating K (default) or reading it from the pool (GPRF_FUSED_FILL=0):
+    the same bits.  GPRF_POTRF_BIG8=0 / GPRF_POTRF_DUAL=0 send everything above 16 tiles through the K pool and the generic
+    kernel, whose row panel is a forward substitution where the register kernels multiply by V_jj on the matrix pipe: the
+    same factor to rounding"""
+    import numpy as np
+    (tmp_path / "wide.py").write_text(WIDE_DRIVER)
+    out = {}
+    for tag, env in (("gen", {}), ("pool", {"GPRF_FUSED_FILL": "0"}), ("generic", {"GPRF_POTRF_BIG8": "0"}),
+                     ("one", {"GPRF_POTRF_DUAL": "0"}), ("queue", {"GPRF_POTRF_DUAL": "2"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        e.update(env)
+        r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        out[tag] = np.load(str(tmp_path / (tag + ".npz")))
+    a = out["gen"]
+    for tag in ("pool", "queue"):
+        b = out[tag]
+        assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
+    for tag in ("generic", "one"):
+        b = out[tag]
+        assert abs(float(a["ll"]) - float(b["ll"])) <= 1e-13 * abs(float(a["ll"])), tag
+        assert np.max(np.abs(a["gX"] - b["gX"])) <= 1e-11 * np.max(np.abs(a["gX"])), tag
+        assert np.allclose(a["gC"], b["gC"], rtol=1e-10, atol=1e-9 * np.max(np.abs(a["gC"]))), tag
+
+
 def test_se_fill_forms_and_grouped_walk_agree_bit_for_bit(tmp_path):
     """K through the pool (GPRF_FUSED_FILL=0): k_fill_se (half the vector-ALU instructions per value) against the
     entry-by-entry k_fill<0,0>; and the solve / gradient grids walked part by part in groups of 64 launch slots against
