@@ -782,34 +782,56 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
     double *Ud = P + 16 * ldp;            // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *Tt = rdt + 16;                // [16][17]  look-ahead tile, row-major
-    double *Gd = Tt + 16 * 17;            // [16][16]  rows of G = D^-1 U_jj (unit triangular: the substitution's operand)
-    double *dvals = Gd + 256;             // [mp]      diagonal of U
+    double *Vd = Tt + 16 * 17;            // [16][16]  V_jj = U_jj^-1, row-major (the row panel's operand)
+    double *dvals = Vd + 256;             // [mp]      diagonal of U
     double *U = pl.U + ur.mat_off;
     const double *Kp = pl.K + ur.mat_off;   // every tile is first read from the K pool (all of them in step 0)
     double *V = pl.V + (size_t)ur.row_off * 16;
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
 
-    // publish a factored diagonal tile (wave 0): global U, LDS Ud / rdt / dvals
+    // publish a factored diagonal tile (wave 0): global U, LDS dvals, and V_jj = U_jj^-1 (LDS + the V pool) — the column
+    // operations of the register kernels' tile_inverse, the same arithmetic in the same order
+    (void)Ud; (void)rdt;
     auto publish = [&](double (&s)[16], double dk, double rdk, int jt, int bad) {
         if (lane < 16) {
             double *Ujj = U + (size_t)(16 * jt) * mp + 16 * jt;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double uv = s[i];                   // the factor left 0 below the diagonal
-                Ujj[(size_t)i * mp + lr] = uv;
-                Ud[i * 16 + lr] = uv;
-            }
-            rdt[lr] = rdk;
+            for (int i = 0; i < 16; ++i) Ujj[(size_t)i * mp + lr] = s[i];      // the factor left 0 below the diagonal
             dvals[16 * jt + lr] = dk;
             if (bad && lane == 0) s_fail = 16 * jt + bad;
+        }
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            int lrc = lr;
+            asm volatile("" : "+v"(lrc));       // (opaque: sixteen loop-invariant doubles would be kept alive across the step loop)
+            v[c] = (c == lrc) ? 1.0 : 0.0;
+        }
+        dpp_src_ready(rdk);
+        static_for<0, 16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            v[k] *= bcast16<k>(rdk);
+            dpp_src_ready(s[k]);
+            static_for<k + 1, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                fnma_bcast16<i>(v[i], s[k], v[k]);
+            });
+        });
+        if (lane < 16) {
+            double *Vj = V + (size_t)jt * 256 + lr * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                Vd[lr * 16 + c] = v[c];
+                Vj[c] = v[c];
+            }
         }
     };
     if (wave == 0) {
         double s[16], dk, rdk;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = Kp[(size_t)i * mp + lr];
-        int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
+        int bad = diag_factor16_ldl<NoEarly, false>(s, lr, &dk, &rdk, nullptr);
         publish(s, dk, rdk, 0, bad);
     }
     __syncthreads();
@@ -831,34 +853,38 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         }
         int ntr = T - j - 1;
         if (ntr == 0) break;
-        // ---- row panel by forward substitution: 64 columns per wave task, one column per lane ----
-        int ncol = 16 * ntr;
+        // ---- row panel on the matrix pipe (round 4, as in the register kernels: the same bits): U_jk = V_jj^T C_jk, a tile per
+        // wave task, four MFMAs each; the next tile's values are in flight while this one's MFMAs run ----
         const double *Csrc = (j == 0) ? Kp : U;   // the trailing matrix: K itself in step 0, U's pool afterwards
-        for (int c0 = 64 * wave; c0 < ncol; c0 += 64 * POTRF_WAVES) {
-            int col = 16 * (j + 1) + c0 + lane;
-            if (c0 + lane < ncol) {
-                double x[16];
-                double *Cc = U + (size_t)(16 * j) * mp + col;
-                const double *Cr = Csrc + (size_t)(16 * j) * mp + col;
+        {
+            double vp[4];
 #pragma unroll
-                for (int a = 0; a < 16; ++a) x[a] = Cr[(size_t)a * mp];
-                // G = D^-1 U_jj one column per lane (in each row of 16 lanes): G[c][a] reaches the FMA by DPP broadcast from
-                // lane a — 16 LDS reads up front instead of one per FMA; unit triangular: the scaling by 1 / U_cc follows
-                // the substitution, off its chain
-                double uc[16];
+            for (int t = 0; t < 4; ++t) vp[t] = Vd[64 * t + 16 * lg + lr];      // V[4 t + lg][lr]: A = V^T
+            int k = j + 1 + wave;
+            const double *Cr = Csrc + (size_t)(16 * j + lg) * mp + 16 * k + lr;
+            double *Cc = U + (size_t)(16 * j + lg) * mp + 16 * k + lr;
+            d4 cur = {0.0, 0.0, 0.0, 0.0};
+            if (k < T) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) uc[c] = Gd[c * 16 + lr];
-                static_for<0, 16>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    if constexpr (c + 1 < 16) fnma_bcast16_ordered<c + 1>(x[c + 1], uc[c], x[c]);
-                    double xs_ = x[c] * rdt[c];       // (1 / U_cc: a uniform LDS read)
-                    Cc[(size_t)c * mp] = xs_;
-                    P[c * ldp + col] = xs_;
-                    static_for<c + 2, 16>([&](auto ac) {
-                        constexpr int a = decltype(ac)::value;
-                        fnma_bcast16_ordered<a>(x[a], uc[c], x[c]);
-                    });
-                });
+                for (int q = 0; q < 4; ++q) cur[q] = Cr[(size_t)(4 * q) * mp];
+            }
+            for (; k < T; k += POTRF_WAVES) {
+                d4 nxt = {0.0, 0.0, 0.0, 0.0};
+                if (k + POTRF_WAVES < T) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nxt[q] = Cr[(size_t)(4 * q) * mp + 16 * POTRF_WAVES];
+                }
+                d4 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r = mfma(vp[q], cur[q], r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    Cc[(size_t)(4 * q) * mp] = r[q];
+                    P[(4 * q + lg) * ldp + 16 * k + lr] = r[q];
+                }
+                Cr += 16 * POTRF_WAVES;
+                Cc += 16 * POTRF_WAVES;
+                cur = nxt;
             }
         }
         GPRF_STAMP(0)
@@ -887,7 +913,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
             double s[16], dk, rdk;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = Tt[r * 17 + lr];
-            int bad = diag_factor16_ldl(s, lr, &dk, &rdk, Gd);
+            int bad = diag_factor16_ldl<NoEarly, false>(s, lr, &dk, &rdk, nullptr);
             publish(s, dk, rdk, i, bad);
         } else {
             // trailing update without tile (j+1,j+1): tile rows i = j+1 .. T-1 dealt cyclically to waves 1..7; along
@@ -939,7 +965,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
         return;
     }
-    potrf_epilogue<POTRF_WAVES>(U, V, P, dvals, lred, mp, T, u, pl);
+    potrf_epilogue<POTRF_WAVES, false>(U, V, P, dvals, lred, mp, T, u, pl);      // (V_jj went out tile by tile)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,15 +101,15 @@ g.close()
 
 def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
     """16 blocks of ~150 points: pairs of 17-22 tiles per edge.  The eight-wave register kernel takes those of up to 20 (160
-    tiles in accumulators, up to 30 waiting in LDS), generating K (default) or reading it from the pool (GPRF_FUSED_FILL=0):
-    the same bits.  GPRF_POTRF_BIG8=0 / GPRF_POTRF_DUAL=0 send everything above 16 tiles through the K pool and the generic
-    kernel, whose row panel is a forward substitution where the register kernels multiply by V_jj on the matrix pipe: the
-    same factor to rounding"""
+    tiles in accumulators, up to 30 waiting in LDS), generating K (default) or reading it from the pool (GPRF_FUSED_FILL=0).
+    GPRF_POTRF_BIG8=0 / GPRF_POTRF_DUAL=0 send everything above 16 tiles through the K pool and the generic kernel,
+    GPRF_POTRF_REG=0 every unit: the same arithmetic per tile in the same order (row panel V_jj^T C_jk on the matrix pipe,
+    the step's products from zero and one addition), the same bits"""
     import numpy as np
     (tmp_path / "wide.py").write_text(WIDE_DRIVER)
     out = {}
     for tag, env in (("gen", {}), ("pool", {"GPRF_FUSED_FILL": "0"}), ("generic", {"GPRF_POTRF_BIG8": "0"}),
-                     ("one", {"GPRF_POTRF_DUAL": "0"}), ("queue", {"GPRF_POTRF_DUAL": "2"})):
+                     ("one", {"GPRF_POTRF_DUAL": "0"}), ("queue", {"GPRF_POTRF_DUAL": "2"}), ("all generic", {"GPRF_POTRF_REG": "0"})):
         e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         e.update(env)
         r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
@@ -117,14 +117,9 @@ def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
         assert r.returncode == 0, r.stdout.decode()[-3000:]
         out[tag] = np.load(str(tmp_path / (tag + ".npz")))
     a = out["gen"]
-    for tag in ("pool", "queue"):
+    for tag in ("pool", "queue", "generic", "one", "all generic"):
         b = out[tag]
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
-    for tag in ("generic", "one"):
-        b = out[tag]
-        assert abs(float(a["ll"]) - float(b["ll"])) <= 1e-13 * abs(float(a["ll"])), tag
-        assert np.max(np.abs(a["gX"] - b["gX"])) <= 1e-11 * np.max(np.abs(a["gX"])), tag
-        assert np.allclose(a["gC"], b["gC"], rtol=1e-10, atol=1e-9 * np.max(np.abs(a["gC"]))), tag
 
 
 def test_se_fill_forms_and_grouped_walk_agree_bit_for_bit(tmp_path):
