@@ -271,32 +271,70 @@ constexpr int GEO_SLH = 0, GEO_CLH = 1, GEO_SNH = 2, GEO_CNH = 3, GEO_Z = 4, GEO
 constexpr int GEO_STRIDE = 8;       // doubles per gathered row of the lld instantiation (XPAD for the Euclidean one)
 
 struct Hav {
-    double a, g, s1, c1, s2, c2, cli, clj, sli, slj;
+    double a, g2, ggp, s1, c1, s2, c2, cli, clj, sli, slj;      // g2 = g^2, ggp = g dg/da (km^2)
 };
+// Round 4: g = 2 R asin(sqrt(a)) is never needed by itself — the kernel wants g^2 (in r^2) and the gradient g dg/da — and both
+// are analytic in a:  asin(sqrt a)^2 = a Q(a) = 1/2 sum_{n>=1} (4a)^n / (n^2 C(2n,n)),  d/da = asin(sqrt a) / sqrt(a (1 - a)) = D(a).
+// For a <= 0.04 (great-circle distance <= 23 degrees = 2560 km: every pair inside a block or between neighbouring blocks of a
+// regional catalogue) two degree-11 Taylor polynomials (exact rational coefficients rounded once; truncation < 1e-17
+// relative) replace a square root + asin (+ a second square root and a division in the gradient): 12 / 24 multiply-adds
+// instead of ~100 / ~190 instructions.  Farther pairs take the closed form (a wave-uniform branch skips it when no lane
+// needs it).
+constexpr double HAV_A0 = 0.04;
+__device__ static __forceinline__ double hav_poly(double a, const double (&c)[12]) {
+    double r = c[11];
+#pragma unroll
+    for (int n = 10; n >= 0; --n) r = __builtin_fma(r, a, c[n]);
+    return r;
+}
+__device__ static __forceinline__ double hav_Q(double a) {
+    const double c[12] = {0x1.0000000000000p+0, 0x1.5555555555555p-2, 0x1.6c16c16c16c17p-3, 0x1.d41d41d41d41dp-4,
+                          0x1.4ce19ae67b348p-4, 0x1.f85d955d36cbbp-5, 0x1.8f0ef795b5337p-5, 0x1.45e5d2ba42ea0p-5,
+                          0x1.10a57fc5a815cp-5, 0x1.d0ef1a8f09124p-6, 0x1.928a4e67e4640p-6, 0x1.60f3b40d2e48ep-6};
+    return hav_poly(a, c);
+}
+__device__ static __forceinline__ double hav_D(double a) {
+    const double c[12] = {0x1.0000000000000p+0, 0x1.5555555555555p-1, 0x1.1111111111111p-1, 0x1.d41d41d41d41dp-2,
+                          0x1.a01a01a01a01ap-2, 0x1.7a463005e918cp-2, 0x1.5d2d18a2fe8d0p-2, 0x1.45e5d2ba42ea0p-2,
+                          0x1.32ba2fbe5d188p-2, 0x1.2295709965ab6p-2, 0x1.14bf15e76d04cp-2, 0x1.08b6c709e2b6ap-2};
+    return hav_poly(a, c);
+}
+template <bool GRAD>
 __device__ static __forceinline__ Hav haversine(const double *gi, const double *gj) {
     Hav h;
     h.s1 = gj[GEO_SLH] * gi[GEO_CLH] - gj[GEO_CLH] * gi[GEO_SLH];      // sin((lat_j - lat_i) / 2)
-    h.c1 = gj[GEO_CLH] * gi[GEO_CLH] + gj[GEO_SLH] * gi[GEO_SLH];
     h.s2 = gj[GEO_SNH] * gi[GEO_CNH] - gj[GEO_CNH] * gi[GEO_SNH];      // sin((lon_j - lon_i) / 2)
-    h.c2 = gj[GEO_CNH] * gi[GEO_CNH] + gj[GEO_SNH] * gi[GEO_SNH];
     h.cli = gi[GEO_CLH] * gi[GEO_CLH] - gi[GEO_SLH] * gi[GEO_SLH];
     h.clj = gj[GEO_CLH] * gj[GEO_CLH] - gj[GEO_SLH] * gj[GEO_SLH];
-    h.sli = 2.0 * gi[GEO_SLH] * gi[GEO_CLH];
-    h.slj = 2.0 * gj[GEO_SLH] * gj[GEO_CLH];
+    if constexpr (GRAD) {
+        h.c1 = gj[GEO_CLH] * gi[GEO_CLH] + gj[GEO_SLH] * gi[GEO_SLH];
+        h.c2 = gj[GEO_CNH] * gi[GEO_CNH] + gj[GEO_SNH] * gi[GEO_SNH];
+        h.sli = 2.0 * gi[GEO_SLH] * gi[GEO_CLH];
+        h.slj = 2.0 * gj[GEO_SLH] * gj[GEO_CLH];
+    }
     double a = h.s1 * h.s1 + h.cli * h.clj * h.s2 * h.s2;
     if (a > 1.0) a = 1.0;
     h.a = a;
-    h.g = 2.0 * asin(sqrt(a)) * EARTH_R_KM;
+    h.ggp = 0.0;
+    if (__builtin_expect(a <= HAV_A0, 1)) {
+        h.g2 = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a * hav_Q(a));
+        if constexpr (GRAD) h.ggp = (2.0 * EARTH_R_KM * EARTH_R_KM) * hav_D(a);
+    } else {
+        double g = 2.0 * asin(sqrt(a)) * EARTH_R_KM;
+        h.g2 = g * g;
+        // g dg/da with dg/da = R / sqrt(a (1 - a)); zero at antipodal points
+        if constexpr (GRAD) h.ggp = a < 1.0 ? g * (EARTH_R_KM / sqrt(a * (1.0 - a))) : 0.0;
+    }
     return h;
 }
 
 template <>
 struct KernFn<1, 1> {
     __device__ static __forceinline__ double value(const KParams &p, const double *gi, const double *gj) {
-        Hav h = haversine(gi, gj);
-        double dk = h.g / p.ls[0];
-        double dd = (gi[GEO_Z] - gj[GEO_Z]) / p.ls[1];
-        double r = sqrt(dk * dk + dd * dd);
+        Hav h = haversine<false>(gi, gj);
+        double il0 = p.inv_ls[0];
+        double dd = (gi[GEO_Z] - gj[GEO_Z]) * p.inv_ls[1];
+        double r = sqrt(h.g2 * (il0 * il0) + dd * dd);
         double s3r = SQRT3 * r;
         return p.sv * (1.0 + s3r) * exp_fast(-s3r);
     }
@@ -305,30 +343,29 @@ struct KernFn<1, 1> {
     // everything up to them — a, g, r, exp — is shared.
     __device__ static __forceinline__ double pair(const KParams &p, const double *gi, const double *gj, bool, double,
                                                   double *dkdxi, double *dkdxj, double *dkdl) {
-        Hav h = haversine(gi, gj);
-        double l0 = p.ls[0], l1 = p.ls[1];
-        double dk = h.g / l0;
+        Hav h = haversine<true>(gi, gj);
+        double il0 = p.inv_ls[0], il1 = p.inv_ls[1];
+        double il02 = il0 * il0, il12 = il1 * il1;
         double dz = gj[GEO_Z] - gi[GEO_Z];
-        double dd = dz / l1;
-        double r = sqrt(dk * dk + dd * dd);
+        double dd = dz * il1;
+        double r = sqrt(h.g2 * il02 + dd * dd);
         double s3r = SQRT3 * r;
         double e = exp_fast(-s3r);
         double k = p.sv * (1.0 + s3r) * e;
         double c = -3.0 * p.sv * e;  // dk/dr = c * r ; r cancels against d r/d(.) = (.)/r
-        // g * dg/d(lon, lat): dg/da = R / sqrt(a(1-a)); zero at coincident / antipodal points
-        double w = 0.0;
-        if (h.a > 0.0 && h.a < 1.0) w = c * h.g * (EARTH_R_KM / sqrt(h.a * (1.0 - h.a))) * DEG2RAD / (l0 * l0);
+        // d k / d(lon, lat) = c (g dg/da) (da / d.) / l0^2, angles in degrees (every da / d. below vanishes at coincident points)
+        double w = c * h.ggp * (DEG2RAD * il02);
         double s22 = h.s2 * h.s2, s1c1 = h.s1 * h.c1;
         double da_dlon = h.cli * h.clj * h.s2 * h.c2;
         dkdxj[0] = w * da_dlon;
         dkdxi[0] = -w * da_dlon;
         dkdxj[1] = w * (s1c1 - h.slj * h.cli * s22);
         dkdxi[1] = w * (-s1c1 - h.sli * h.clj * s22);
-        double tz = c * dz / (l1 * l1);
+        double tz = c * dz * il12;
         dkdxj[2] = tz;
         dkdxi[2] = -tz;
-        dkdl[0] = -c * h.g * h.g / (l0 * l0 * l0);
-        dkdl[1] = -c * dz * dz / (l1 * l1 * l1);
+        dkdl[0] = -c * h.g2 * (il02 * il0);
+        dkdl[1] = -c * dz * dz * (il12 * il1);
         return k;
     }
 };
@@ -4354,6 +4391,11 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
         } else if (ut.max_T <= 18) {      // (an exact 16-tile instantiation is slower: 82 vs 79 us, C4 674 vs 640)
             if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 20) {
+            // (two panels of 19 tile columns + V_rr fill half of the CU's LDS exactly: two workgroups per CU, as many registers
+            // each as the accumulators of 20 tiles need — the seismic configuration's pairs of 312 points)
+            if (pm) hipLaunchKernelGGL((k_solve_panel<20, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<20, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else {
             if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
