@@ -2529,7 +2529,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
 template <int DIST, int KERN, bool HAVEK, int FAST>
-__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
     // reductions at the end find them in LDS instead of starting with exposed global loads
@@ -2756,15 +2756,15 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
                     if constexpr (GC) gc_l[d] += gd * delta;
                 }
             } else {
-                if (ok) {
+                {
+                    // (branch-free: padding entries have Mij = 0 and finite derivatives — the four entries of a lane are
+                    // independent chains the scheduler can interleave)
                     double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
                     double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
-                    if (i != j) {
+                    const double Mo = (i != j) ? Mij : 0.0;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) csd[d] += Mij * dkdxj[d];
-                    } else {
-                        gc_tr += Mij;
-                    }
+                    for (int d = 0; d < 3; ++d) csd[d] += Mo * dkdxj[d];
+                    gc_tr += (i == j) ? Mij : 0.0;
                     gc_sv += Mij * k;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
@@ -2817,7 +2817,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 3)
                         if constexpr (GC) gc_l[d] += 2.0 * gd * delta;
                     }
                 } else {
-                    if (ok) {
+                    {
                         double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
                         double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
 #pragma unroll
@@ -4557,6 +4557,9 @@ void launch_pair_max(int dist_id, int kern_id, const double *X, int dx, const in
 // k_done: the last kernel of a host-in / host-out evaluation: everything before it on the stream has completed
 // (kernel boundary), so one store of the evaluation's sequence number into pinned host memory tells a polling host
 // that the result is there — a few microseconds instead of the runtime's stream-synchronisation path.
+// (Round 4 measured the word written from INSIDE the assembly instead — every workgroup fences its result stores at system
+// scope and takes a ticket, the last one stores the word; one launch less: 0.409 ms per step against 0.387 — 314 workgroups'
+// system-scope fences cost four times what the 4 us launch does.  Dropped.)
 __global__ void k_done(int32_t *flag, int32_t seq) {
     if (threadIdx.x == 0) {
         __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
