@@ -16,8 +16,8 @@ def short(name):
     # the two instantiations that differ by where K comes from (demangled or mangled spelling)
     if "k_potrf_reg2" in name:
         return "k_potrf_reg2_gen"
-    if "k_potrf_reg8" in name:
-        return "k_potrf_reg8_gen"
+    if "k_potrf_reg8" in name:      # k_potrf_reg8<SLOTS, GEN, RA>: K generated, or read from the pool (lld / Matern, forced fills)
+        return "k_potrf_reg8_pool" if ("<20, false" in name or "ILi20ELb0E" in name) else "k_potrf_reg8_gen"
     if "k_potrf_reg" in name:
         return "k_potrf_reg_gen" if (", true>" in name or "ELb1E" in name) else "k_potrf_reg"
     if "k_mgrad" in name and ("<0, 0, true>" in name or "ILi0ELi0ELb1E" in name):
