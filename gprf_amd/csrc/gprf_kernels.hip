@@ -2106,8 +2106,8 @@ __global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl
 }
 
 
-constexpr int SOLVE_PANEL_MAXT = 28;  // largest k_solve_panel instantiation (accumulators: 28 tiles x 8 registers,
-                                      // one workgroup per CU: 448 points cover the seismic configuration's pairs)
+constexpr int SOLVE_PANEL_MAXT = 32;  // largest k_solve_panel instantiation (accumulators: 32 tiles x 8 registers, two panels
+                                      // of 31 tile columns = 127 KB of LDS, one workgroup per CU: units of up to 512 points)
 
 // k_solve_panel: the same forward substitution with the U row panel of each step staged ONCE per workgroup in LDS
 // (cooperative, coalesced loads of panel r+1 overlap step r's MFMAs; one barrier per step), so the four waves
@@ -4396,13 +4396,16 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
             // each as the accumulators of 20 tiles need — the seismic configuration's pairs of 312 points)
             if (pm) hipLaunchKernelGGL((k_solve_panel<20, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<20, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 28) {      // (448 points cover the seismic configuration's pairs at every block size below 210)
+            if (pm) hipLaunchKernelGGL((k_solve_panel<28, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<28, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else {
             if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         }
         return;
     }
-    // units of more than 448 points: accumulators no longer fit the register budget -> LDS-broadcast form
+    // units of more than 512 points: accumulators no longer fit the register budget -> LDS-broadcast form
     // (its grid covers units of up to 1024 points; larger ones are skipped here: launch_big_solve)
     UnitTab uts = ut;
     if (uts.max_T > SMALL_MAX_T) uts.max_T = SMALL_MAX_T;
