@@ -1123,6 +1123,9 @@ constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
 // 30 in row-major order (row 0 and part of row 1: they retire first and are updated at most once) wait in LDS
 constexpr int POTRF_REG8_MAXT = 20;
 constexpr int POTRF_REG8_LDP = 336;  // >= 16 * 20, = 16 mod 32
+// ... and 21 .. 28 tiles (GW): the tiles beyond the 160 accumulator slots wait in the U pool, at their own place
+constexpr int POTRF_REG8W_MAXT = 28;
+constexpr int POTRF_REG8W_LDP = 464; // >= 16 * 28, = 16 mod 32
 constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13, = 16 mod 32
 // ------------------------------------------------------------------------------------------------
 // k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
@@ -1150,10 +1153,16 @@ constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13
 // DK (GEN only): 0 = ("euclidean","se"), coordinates of XPAD doubles per point; 1 = ("lld","matern32"), the GEO_STRIDE-double
 // half-angle records (KernFn<1,1>::value per entry, k_fill<1,1>'s definition)
 // RA ("run-ahead", two-per-CU / eight-wave instantiations): no workgroup barrier inside the step loop — see the RA block.
-template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0, bool RA = false>
+// GW (eight-wave instantiation, K from the pool): units of up to 28 tiles per edge — the (up to 218) tiles beyond the
+// accumulator slots wait in GLOBAL memory instead of LDS: in the U pool, each at its own final place (nobody else touches a
+// tile of U before its row is solved), read and written through the CU's L1 / the L2 like the generic kernel's whole trailing
+// matrix — a fraction of that kernel's traffic (the first rows only, and only until they retire).  Waves of one workgroup
+// share the CU's L1: a store is visible to the other waves behind s_waitcnt vmcnt(0) + the workgroup barrier.
+template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0, bool RA = false, bool GW = false>
 __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &pl, int stamps, int reg_maxT, const KParams &kp,
-                                               int which) {
+                                               int which, int min_T = 0) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
+    static_assert(!GW || (RW == 8 && !GEN && !RA), "waiting tiles in the U pool: the eight-wave kernel reading the K pool");
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[RW];
@@ -1198,7 +1207,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     const int u = ur.u;
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
-    if (T > reg_maxT) return;             // k_potrf's units
+    if (T > reg_maxT || T < min_T) return;      // k_potrf's units; another instantiation's
     if (m == 0) {
         if (threadIdx.x == 0) { pl.logdet[u] = 0.0; pl.info[u] = 0; }
         return;
@@ -1212,8 +1221,8 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
     // solved panel then goes to global memory inside its own step (copy_now below), never from the other buffer
     constexpr bool WHOLE_CU = WPS == 1 || RW == 8;     // one workgroup per CU: the wide pitch (units of up to 16 / 20 tiles)
-    constexpr int MT = RW == 8 ? POTRF_REG8_MAXT : POTRF_REG_MAXT_C;
-    constexpr int ldp = RW == 8 ? POTRF_REG8_LDP : (WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP);
+    constexpr int MT = RW == 8 ? (GW ? POTRF_REG8W_MAXT : POTRF_REG8_MAXT) : POTRF_REG_MAXT_C;
+    constexpr int ldp = RW == 8 ? (GW ? POTRF_REG8W_LDP : POTRF_REG8_LDP) : (WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP);
     constexpr int NPB = WPS == 1 ? 2 : 1;
     double *P0 = lds;                     // [NPB][16][ldp] row panel j of U in buffer j & (NPB - 1): a pure-factor wave 0
     double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
@@ -1380,11 +1389,18 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
     }
     // the tiles that wait in LDS (n_lds > 0: units of 19, 20 tiles per edge in the eight-wave kernel), as they are (not negated)
+    // (GW: in the U pool, at their own place)
     for (int t = wave; t < n_lds; t += RW) {
         int i = 0, rs = 0, rl = T - 1;
         while (t >= rs + rl) { rs += rl; --rl; ++i; }
         const int k = i + 1 + (t - rs);
-        if constexpr (GEN) {
+        if constexpr (GW) {
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = Kp[(size_t)(16 * i + 4 * q) * mp + 16 * k + glane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[(size_t)(16 * i + 4 * q) * mp + 16 * k + glane] = v[q];
+        } else if constexpr (GEN) {
             double kv[1][4];
             int pk[1] = {32 * i + k};
             kgen(std::integral_constant<int, 1>{}, pk, kv, 1.0);
@@ -1640,7 +1656,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #pragma unroll
         for (int t = 0; t < 4; ++t) va[t] = -Vb[dl + 64 * t];            // -V[4 t + lg][lr]
         // byte offset of this lane's first row (16 j + lg) in U, column lr (a unit's matrix is at most 512 KB: 32 bits)
-        const unsigned ub = ((unsigned)(16 * j + lg) * (unsigned)mp + (unsigned)lr) * 8u;
+        const unsigned ub = ((unsigned)(16 * j + (dl >> 4)) * (unsigned)mp + (unsigned)(dl & 15)) * 8u;
         const unsigned rstep = 32u * (unsigned)mp;                       // four rows down, in bytes
         d4 tt[2];
         int pend = -1;                          // tile column of the product still settling in tt[parity]
@@ -1697,6 +1713,18 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             double vp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) vp[t] = -va[t];
+            if constexpr (GW) {
+                const unsigned gl = (unsigned)((dl >> 4) * mp + (dl & 15));      // (from the step's opaque copy: see lb / dl)
+                for (int t = rsj + wave; t < t1; t += RW) {
+                    const double *Cr = U + (size_t)(16 * j) * mp + 16 * (j + 1 + (t - rsj)) + gl;
+                    double b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = Cr[(size_t)(4 * q) * mp];
+                    d4 r = {0.0, 0.0, 0.0, 0.0};
+                    mfma4_vgpr(r, vp, b);
+                    flush(j + 1 + (t - rsj), r);
+                }
+            } else
             for (int t = rsj + wave; t < t1; t += RW) {
                 double b[4];
 #pragma unroll
@@ -1711,6 +1739,28 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     auto update_lds_tiles = [&](int j, int lb, int dl) {
         const int rs1 = (j + 1) * T - ((j + 1) * (j + 2)) / 2;      // first tile of row j + 1
         if (rs1 >= n_lds || wave == 0) return;
+        if constexpr (GW) {
+            int i = j + 1, r0_ = rs1, rl = T - 2 - j;
+            const unsigned gl = (unsigned)((dl >> 4) * mp + (dl & 15));
+            for (int t = rs1 + (wave - 1); t < n_lds; t += NW) {
+                while (t >= r0_ + rl) { r0_ += rl; --rl; ++i; }
+                const int k = i + 1 + (t - r0_);
+                double *Cp = U + (size_t)(16 * i) * mp + 16 * k + gl;
+                double c[4], a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = Cp[(size_t)(4 * q) * mp];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = -P[(4 * q) * ldp + 16 * i + lb];
+                    b[q] = P[(4 * q) * ldp + 16 * k + lb];
+                }
+                d4 sacc = {0.0, 0.0, 0.0, 0.0};
+                mfma4_vgpr(sacc, a, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Cp[(size_t)(4 * q) * mp] = c[q] + sacc[q];
+            }
+            return;
+        }
         for (int t = rs1 + (wave - 1); t < n_lds; t += NW) {
             int i = j + 1, r0_ = rs1, rl = T - 2 - j;
             while (t >= r0_ + rl) { r0_ += rl; --rl; ++i; }
@@ -1890,7 +1940,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         P = P0 + (j & (NPB - 1)) * 16 * ldp;
         if (wave == 0) {
             // U_jj (published in LDS by the last look-ahead) -> global, off the critical path
-            for (int e = lane; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
+            for (int e = dl; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
         }
         if (mine) {
             solve_rows(j, s_lo, s_hi, lb, dl, Vd0);
@@ -1898,6 +1948,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
         GPRF_STAMP(0)
         GPRF_STAMP2(3)
+        if constexpr (GW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the waiting tiles' stores: visible to the other waves
         lds_barrier();
         GPRF_STAMP(1)
         GPRF_STAMP2(4)
@@ -1913,6 +1964,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         GPRF_STAMP(2)
         GPRF_STAMP2(5)
         GPRF_STAMP3(2)
+        if constexpr (GW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         GPRF_STAMP(3)
         GPRF_STAMP2(6)
@@ -1987,6 +2039,13 @@ template <int SLOTS, bool GEN, bool RA = false>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8(UnitTab ut, Pools pl, int stamps,
                                                                                            int reg_maxT, KParams kp, int which) {
     potrf_reg_body<8, SLOTS, GEN, 2, 0, RA>(ut, pl, stamps, reg_maxT, kp, which);
+}
+// ... units of 21 .. 28 tiles per edge (and, in a launch that has such units, every smaller one too), K from the pool: the
+// tiles beyond the accumulator slots wait in the U pool (GW)
+template <int SLOTS>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8w(UnitTab ut, Pools pl, int stamps,
+                                                                                            int reg_maxT, KParams kp, int which, int min_T) {
+    potrf_reg_body<8, SLOTS, false, 2, 0, false, true>(ut, pl, stamps, reg_maxT, kp, which, min_T);
 }
 template <int RW, int SLOTS, bool GEN, bool RA = false>
 __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg2(UnitTab ut, Pools pl, int stamps,
@@ -3456,7 +3515,7 @@ void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
 // dynamic LDS above 48 KB has to be opted into per kernel AND per device: remembers the largest size already
 // granted for (kernel slot, current device)
 static bool lds_needs_optin(int kernel_slot, size_t lds) {
-    static size_t granted[10][64] = {};
+    static size_t granted[12][64] = {};
     if (lds <= 48 * 1024) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
@@ -4124,6 +4183,7 @@ static bool potrf_use_reg(const UnitTab &ut) {
     (void)ut;
     return (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : true;
 }
+static bool potrf_gw();
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
     const bool off = e && e[0] == '0';
@@ -4133,8 +4193,14 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     // GPRF_LLD_GEN=1 turns it on.
     static const bool lld_gen = [] { const char *g = getenv("GPRF_LLD_GEN"); return g && g[0] == '1'; }();
     const bool se = dist_id == 0 && kern_id == 0, lld = dist_id == 1 && kern_id == 1 && lld_gen;
+    // a launch with units of more than 20 tiles per edge goes through the K pool as a whole: ONE eight-wave kernel then takes
+    // every unit of up to 28 tiles (waiting tiles in the U pool) — behind the generating kernels it would run by itself, a
+    // unit's whole chain later (measured, 49 blocks of ~184 points + 156 pairs of 20-27 tiles: fill + Cholesky 32 + 281 us
+    // against 28 + 439)
+    if (ut.max_T > 20 && potrf_gw()) return false;
     return !off && (se || lld) && ut.n_ids > 0 && potrf_use_reg(ut);
 }
+constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
 // (the eight-wave instantiation — the large-unit kernel of the two-queue SE path, and the non-generating register kernel —
 // takes units of up to POTRF_REG8_MAXT tiles per edge: 140 .. 160 tiles in accumulators, up to 30 more waiting in LDS)
 static bool potrf_big8() {
@@ -4143,13 +4209,25 @@ static bool potrf_big8() {
 }
 bool potrf_dual_enabled();
 int potrf_gen_maxT(int dist_id) { return dist_id == 0 && potrf_dual_enabled() && potrf_big8() ? POTRF_REG8_MAXT : POTRF_REG_MAXT_C; }
+// units of 21 .. 28 tiles per edge on the eight-wave kernel with its waiting tiles in the U pool (GPRF_POTRF_GW=0: the generic
+// kernel, diagnostics)
+static bool potrf_gw() {
+    static const bool on = [] { const char *e = getenv("GPRF_POTRF_GW"); return !(e && e[0] == '0'); }();
+    return on && potrf_big8();
+}
+static void launch_reg8w(dim3 grid, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, const KParams &kp, int min_T) {
+    const int capT = ut.max_T < POTRF_REG8W_MAXT ? ut.max_T : POTRF_REG8W_MAXT;
+    const size_t lds = (size_t)(16 * POTRF_REG8W_LDP + 256 + 16 + 256 + 16 * POTRF_REG8W_MAXT + 256 * capT) * sizeof(double);
+    if (lds_needs_optin(9, lds))
+        (void)hipFuncSetAttribute((const void *)k_potrf_reg8w<POTRF_SMALL_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_potrf_reg8w<POTRF_SMALL_SLOTS>), grid, dim3(512), lds, s, ut, p, stamps, POTRF_REG8W_MAXT, kp, 0, min_T);
+}
 // LDS of the eight-wave instantiation for units of up to capT tiles per edge (doubles)
 static size_t potrf_reg8_lds(int capT, int xs_stride) {
     const int total = capT * (capT - 1) / 2, n_lds = total > 8 * 20 ? total - 8 * 20 : 0;
     return (size_t)(16 * POTRF_REG8_LDP + 256 + 16 + 256 + 16 * POTRF_REG8_MAXT + 256 * capT + 16 * capT * xs_stride + 256 * n_lds);
 }
 
-constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
 constexpr int POTRF_SMALL_MAXT = 13;
 bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation only (diagnostics)
     static const bool on = [] { const char *e = getenv("GPRF_POTRF_DUAL"); return !(e && e[0] == '0'); }();
@@ -4244,6 +4322,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
     auto launch_generic = [&]() {
         if (ut.max_T <= reg_maxT) return;
+
         const int capG = ut.max_T < SMALL_MAX_T ? ut.max_T : SMALL_MAX_T;      // (larger units: launch_big_potrf)
         size_t ldsg = (size_t)(16 * (16 * capG + 16) + 256 + 16 + 16 * 17 + 256 + 16 * capG) * sizeof(double);
         if (lds_needs_optin(1, ldsg))
@@ -4361,7 +4440,13 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         }
         if (wide) {
             // the K pool's units of up to 20 tiles, eight waves a unit, one launch over the launch order (longest units first)
-            launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
+            if (ut.max_T > POTRF_REG8_MAXT && potrf_gw()) {
+                // (a launch with units above 20 tiles: ONE instantiation for everything of up to 28 — two launches on one
+                // stream would run one after the other)
+                launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, 0);
+                reg_maxT = POTRF_REG8W_MAXT;
+            } else
+                launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
             launch_generic();
             return;
         }

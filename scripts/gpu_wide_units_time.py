@@ -1,9 +1,6 @@
 """Stage times with units of 21-30 tiles per edge (16 blocks of ~206 points + their pairs, SE kernel; FILL=1: K through the pool):
     python scripts/gpu_wide_units_time.py [n] [blocks]
-(round 4 measured the eight-wave register kernel with the tiles beyond its 160 accumulator slots waiting in the U pool for units
-of 21..28 tiles against the generic kernel with this script: 676-757 vs 480 us at n = 3300 / 16 blocks, 772-866 vs 684 at
-n = 13200 / 64 blocks — the waiting tiles' read-modify-write round trips through L2, up to 31 per worker and step, cost more than
-the generic kernel's whole trailing matrix; dropped)"""
+(A/B: GPRF_POTRF_GW=0 sends the units of 21..28 tiles to the generic kernel instead of k_potrf_reg8w)"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -440,8 +440,9 @@ def test_generated_and_filled_kernel_matrices_give_the_same_evaluation(monkeypat
 def test_one_pair_over_256_points_leaves_the_other_units_generated(monkeypatch):
     """The kernel-matrix source is decided per unit (round 2 decided per launch: one pair growing past 256 points sent every
     unit through the K pool).  A north-star-shaped partition in which ONE block is crowded so that its pairs exceed 256
-    points: those units take k_fill + the generic Cholesky, all others are generated inside the register-resident one; the
-    result equals the all-through-the-pool evaluation to rounding and the oracle's."""
+    points: units of up to 320 points are generated inside the register-resident Cholesky whatever their neighbours' sizes
+    (round 4: up to 20 tiles; a launch with larger units goes through the pool as a whole); the result equals the
+    all-through-the-pool evaluation to rounding and the oracle's."""
     from gprf_amd import Blocker, grid_centers, GPCov
     from gprf_amd.gprf import GPRF
     from oracle.gprf_ref import GPRFRef

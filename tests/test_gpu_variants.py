@@ -84,15 +84,19 @@ import sys
 import numpy as np
 from gprf_amd import Blocker, grid_centers, GPCov
 from gprf_amd.gprf import GPRF
+import os
 rng = np.random.RandomState(31)
-n = 2400
+n = int(os.environ.get("WIDE_N", "2400"))
 X = rng.rand(n, 2)
 Y = rng.randn(n, 7)
 b = Blocker(grid_centers(16))
 g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.09, 0.11], "euclidean", "se"), 0.02, neighbors=b.neighbors())
 sz = [len(u) for u in g.block_idxs]
 tiles = sorted(set((sz[i] + sz[j] + 15) // 16 for i, j in g.neighbors))
-assert tiles[0] >= 17 and 19 in tiles and 20 in tiles and tiles[-1] > 20, tiles
+if n == 2400:
+    assert tiles[0] >= 17 and 19 in tiles and 20 in tiles and tiles[-1] > 20, tiles
+else:
+    assert tiles[0] >= 21 and tiles[-1] > 28 and len([t for t in tiles if 21 <= t <= 28]) >= 5, tiles
 ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
 np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
 g.close()
@@ -118,6 +122,28 @@ def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
         out[tag] = np.load(str(tmp_path / (tag + ".npz")))
     a = out["gen"]
     for tag in ("pool", "queue", "generic", "one", "all generic"):
+        b = out[tag]
+        assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
+
+
+def test_units_of_21_to_28_tiles_wait_in_the_U_pool(tmp_path):
+    """16 blocks of ~206 points: pairs of 24-30 tiles per edge.  A launch with units above 20 tiles goes through the K pool as a
+    whole and ONE eight-wave register kernel takes every unit of up to 28 tiles, the tiles beyond its 160 accumulator slots
+    waiting in the U pool (in place, through L2); the 29- and 30-tile pairs take the generic kernel.  GPRF_POTRF_GW=0: the
+    generating kernels for units of up to 20 tiles, the generic kernel above — the same bits"""
+    import numpy as np
+    (tmp_path / "wide.py").write_text(WIDE_DRIVER)
+    out = {}
+    for tag, env in (("gw", {}), ("pool", {"GPRF_FUSED_FILL": "0"}), ("generic", {"GPRF_POTRF_GW": "0"}),
+                     ("pool generic", {"GPRF_FUSED_FILL": "0", "GPRF_POTRF_GW": "0"}), ("all generic", {"GPRF_POTRF_REG": "0"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), WIDE_N="3300")
+        e.update(env)
+        r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag.replace(" ", "_") + ".npz"))], cwd=str(tmp_path),
+                           env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        out[tag] = np.load(str(tmp_path / (tag.replace(" ", "_") + ".npz")))
+    a = out["gw"]
+    for tag in ("pool", "generic", "pool generic", "all generic"):
         b = out[tag]
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
 

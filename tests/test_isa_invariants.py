@@ -45,6 +45,7 @@ def _setting(lines, mangled_part, key):
                                         ("12k_potrf_reg2ILi4ELi20ELb1ELb0E", 20), ("12k_potrf_reg8ILi20ELb1ELb0E", 20),
                                         ("12k_potrf_reg2ILi4ELi20ELb1ELb1E", 20), ("12k_potrf_reg8ILi20ELb1ELb1E", 20),      # run-ahead forms
                                         ("12k_potrf_reg8ILi20ELb0ELb0E", 20),      # K read, eight waves (units of up to 20 tiles)
+                                        ("13k_potrf_reg8wILi20E", 20),             # ... up to 28 tiles, waiting tiles in the U pool
                                         ("15k_potrf_reg_lldILi4ELi32E", 32)])
 def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa, inst, slots):
     body = _function(isa, inst)
