@@ -2173,14 +2173,18 @@ constexpr int SOLVE_PANEL_MAXT = 32;  // largest k_solve_panel instantiation (ac
 // — four RHS column blocks — share every U tile and each update MFMA costs one conflict-free ds_read.
 // Each wave's tiles for all rows stay in MFMA accumulators; the freshly solved tile is already in B-operand layout
 // (accumulator register q = rows 4q+lg), so the right-looking updates chain through registers.
-template <int MAXT, int WPS, bool PM>
+// NBUF = 1 (round 4, units of 21 .. 26 tiles): ONE panel buffer — 52 KB + V_rr instead of 104: TWO workgroups per CU where the
+// double-buffered form has one; the next panel is requested behind a second barrier (nobody reads the current one any more) and
+// its round trip is exposed to this workgroup — the other workgroup of the CU computes meanwhile
+template <int MAXT, int WPS, bool PM, int NBUF = 2>
 __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, int dy) {
     // panel columns are stored RELATIVE to the first column right of the diagonal tile (16(r+1)): a step loads and
     // keeps only what its updates read.  (LDP/16) odd: lane groups 32 banks apart
     constexpr int LDP = 16 * ((MAXT - 1) | 1);
     constexpr int NCH = (16 * (MAXT - 1) + 127) / 128;
-    __shared__ __attribute__((aligned(16))) double panel[2][16 * LDP];
+    __shared__ __attribute__((aligned(16))) double panel[NBUF][16 * LDP];
     __shared__ double Vl[2][256];
+    static_assert(NBUF == 2 || 16 * MAXT * sizeof(int32_t) <= sizeof(double) * 512, "the row -> point table aliases Vl");
     int slot_, part_;
     int nI = (ut.max_T + 3) >> 2;                // parts 0..nI-1: identity column blocks 4p+wave; part nI: Y blocks
     WgTrace trace(ut, pl, 1);
@@ -2218,7 +2222,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     // first (one coalesced load), so that the gather itself is a single round of independent loads
     // (in the second panel buffer, which the step loop writes only after its first barrier: the two panels + V already
     // fill half of the CU's LDS exactly, and one more kilobyte would halve the occupancy)
-    int32_t *s_upt = reinterpret_cast<int32_t *>(&panel[1][0]);
+    int32_t *s_upt = reinterpret_cast<int32_t *>(NBUF == 2 ? &panel[NBUF - 1][0] : &Vl[0][0]);
     if (is_y) {
         // (every tile of the instantiation; a lane's four rows lg + 4q of a tile next to each other: one 16-byte read)
         for (int e = tid; e < 16 * MAXT; e += 256)
@@ -2251,6 +2255,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
                 acc[r][q] = ok ? v : 0.0;
             }
         });
+        if constexpr (NBUF == 1) __syncthreads();      // the table (in Vl) has been read: the step loop may write V_rr there
     } else {
         static_for<0, MAXT>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
@@ -2275,7 +2280,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
         constexpr int nch = decltype(nchc)::value;
         int ncols = mp - 16 * (r + 1);
         const double *Ur = U + (size_t)(16 * r + 4 * wave) * mp + 16 * (r + 1) + 2 * (unsigned)lane;   // wave-uniform + lane
-        double *dst = panel[r & 1] + (4 * wave) * LDP;                                                  // wave-uniform
+        double *dst = panel[r & (NBUF - 1)] + (4 * wave) * LDP;                                         // wave-uniform
 #pragma unroll
         for (int k = 0; k < nch; ++k) {
             if (128 * k < ncols) {                                                     // uniform
@@ -2321,7 +2326,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     static_for<0, MAXT>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if (r >= rmin && r < T) {                 // uniform over the workgroup
-            double *buf = panel[r & 1];
+            double *buf = panel[r & (NBUF - 1)];
             constexpr int nch_r = (16 * (MAXT - 1 - r) + 127) / 128;          // chunks a unit of MAXT tiles needs at this step
             if constexpr (!GLDS) {
                 int ncols = mp - 16 * (r + 1);
@@ -2340,7 +2345,9 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
             GPRF_SST(0)
             lds_barrier();                        // LDS only (register staging: no wait for the W / Z stores of the step before)
             GPRF_SST(1)
-            if (r + 1 < T) fetch(r + 1, std::integral_constant<int, (16 * (MAXT - 2 - r) + 127) / 128>{});
+            if constexpr (NBUF == 2) {
+                if (r + 1 < T) fetch(r + 1, std::integral_constant<int, (16 * (MAXT - 2 - r) + 127) / 128>{});
+            }
             GPRF_SST(2)
             if (live && r >= r0) {
                 const double *vl = Vl[r & 1] + lg * 16 + lr;
@@ -2373,6 +2380,12 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
                     }
                 });
                 GPRF_SST(4)
+            }
+            if constexpr (NBUF == 1) {
+                if (r + 1 < T) {              // (uniform) the one buffer is free when every wave has finished its updates
+                    lds_barrier();
+                    fetch(r + 1, std::integral_constant<int, (16 * (MAXT - 2 - r) + 127) / 128>{});
+                }
             }
         }
     });
@@ -4481,6 +4494,9 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
             // each as the accumulators of 20 tiles need — the seismic configuration's pairs of 312 points)
             if (pm) hipLaunchKernelGGL((k_solve_panel<20, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<20, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 26) {      // (one panel buffer, two workgroups per CU: the paper-scale catalogue's pairs of 390 points)
+            if (pm) hipLaunchKernelGGL((k_solve_panel<26, 2, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<26, 2, false, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else if (ut.max_T <= 28) {      // (448 points cover the seismic configuration's pairs at every block size below 210)
             if (pm) hipLaunchKernelGGL((k_solve_panel<28, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<28, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);

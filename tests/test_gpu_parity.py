@@ -289,7 +289,11 @@ def test_device_reblocking_matches_host_and_oracle():
                                          (2, 9, [112, 112, 120, 120, 128, 128, 127]),
                                          # the seismic configuration's largest pairs (blocks of up to 209 events):
                                          # 27 and 28 tiles, the one-workgroup-per-CU instantiation of k_solve_panel
-                                         (3, 5, [209, 209, 30, 224, 224])])
+                                         (3, 5, [209, 209, 30, 224, 224]),
+                                         # the paper-scale catalogue's shape: leaves of 195 points, pairs of 25 tiles — the
+                                         # eight-wave Cholesky with 140 tiles waiting in the U pool, the single-buffer
+                                         # two-per-CU k_solve_panel (largest unit 26 tiles), dy beyond one 16-column block
+                                         (3, 50, [195, 195, 196, 60, 208])])
 def test_random_shapes_against_oracle(dx, dy, sizes):
     """SE kernel with 1-3 input dimensions, 1..64 output columns (64 = the padded width), ragged block sizes incl.
     tile-boundary cases (16, 64, 255/257 -> pair of 512), chain of pairs + one long-range pair."""
