@@ -670,6 +670,37 @@ def main():
                             "algorithmic_TFLOPs": fl5["total"] * c5 / 1e12,
                             "fill_GBps": (fl5["fill_bytes"] / (st5["fill"] * 1e-3) / 1e9) if (n_members == 1 and st5["fill"] > 0) else None}
         g5.close()
+        del g5
+        # the same at the catalogue's paper scale (about 1e5 events: leaves of 195 points, pairs of 390 = 25 tiles per edge —
+        # the eight-wave Cholesky with its overflow tiles waiting in the U pool, the single-buffer forward substitution)
+        n6 = 100000
+        X6 = seismic.synthetic_events(n6, seed=0)
+        Y6 = np.random.RandomState(1).randn(n6, 50)
+        blocks6, reblock6 = seismic.pdtree_cluster(X6, 210)
+        g6 = GPRF(X6, Y6, reblock6, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6, **kw5)
+        rng6 = np.random.RandomState(3)
+        X6s = [np.ascontiguousarray(X6 + 1e-4 * k * rng6.randn(*X6.shape)) for k in range(2)]
+        c6, c6ms, c6samples = sequential_rate(g6, X6s, 10, 2, True, 3)
+        g6._ctx.set_timing(True, reset=True)
+        for k in range(6):
+            g6.update_X(X6s[k % 2])
+            g6.llgrad(grad_X=True, grad_cov=True)
+        barrier()
+        st6 = g6._ctx.get_timing()
+        g6._ctx.set_timing(False)
+        st6.pop("count")
+        if rank == 0:
+            sz6 = gdist.unit_sizes(g6.block_idxs, g6.neighbors)
+            fl6 = algorithmic_flops(sz6, 50)
+            result["c5_paper_scale"] = {"workload": "STAND-IN catalogue at paper scale (synthetic_events, n=%d), lld / matern32, split-tree blocks "
+                                                    "< 210 (%d blocks), threshold 0.6 (%d pairs, largest unit %d points), yd=50, task xcov" % (
+                                                        n6, len(g6.block_idxs), len(g6.neighbors), int(sz6.max())),
+                                        "evals_per_s": c6, "ms_per_eval": c6ms, "steps": 10, "distinct_X": 2,
+                                        "ms_per_eval_samples": [round(v, 4) for v in c6samples],
+                                        "stages_ms": {k2: round(v, 5) for k2, v in st6.items()},
+                                        "algorithmic_TFLOPs": fl6["total"] * c6 / 1e12}
+        g6.close()
+        del g6, X6, Y6, X6s
 
     if n_members == 1 and not args.only_north_star and not args.no_cpu_baseline:
         if affinity_before is not None:
