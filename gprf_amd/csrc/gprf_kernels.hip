@@ -4473,6 +4473,13 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     launch_generic();
 }
 
+// units of 13 .. 16 tiles: the single-buffer form at THREE workgroups per CU (35 KB of LDS, 157 VGPRs) against the
+// double-buffered 18-tile instantiation's two — round 4, measured: C3 87 -> 79 us, C4 633 -> 596 (GPRF_SOLVE16_SINGLE=0: the
+// double-buffered form; diagnostics)
+static bool solve16_single() {
+    static const bool on = [] { const char *e = getenv("GPRF_SOLVE16_SINGLE"); return !(e && e[0] == '0'); }();
+    return on;
+}
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0) return;
     // PM: the grid walked part by part (part_major_map) — launches several rounds deep; GPRF_PART_MAJOR=0 / 1 forces
@@ -4486,6 +4493,9 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
         if (ut.max_T <= 12) {
             if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 16 && solve16_single()) {      // (one panel buffer, three workgroups per CU)
+            if (pm) hipLaunchKernelGGL((k_solve_panel<16, 3, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else hipLaunchKernelGGL((k_solve_panel<16, 3, false, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else if (ut.max_T <= 18) {      // (an exact 16-tile instantiation is slower: 82 vs 79 us, C4 674 vs 640)
             if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);

@@ -74,6 +74,7 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"}),
                       ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"}),
                       ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"}),
+                      ("forward substitution with two panel buffers, two workgroups per CU", {"GPRF_SOLVE16_SINGLE": "0"}),
                       ("the Cholesky's step loop without workgroup barriers (run-ahead form)", {"GPRF_POTRF_RA": "1"}),
                       ("run-ahead, one queue", {"GPRF_POTRF_RA": "1", "GPRF_POTRF_DUAL": "2"})):
         assert run_variant(tmp_path, env) == base, name
