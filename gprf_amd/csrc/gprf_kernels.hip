@@ -4553,10 +4553,15 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // (only while the launch is a few rounds deep: with thousands of units the ten workgroups of a unit would run far apart
     // and each fetch the unit's W / At from HBM again — C4: 809 vs 775 us)
-    const int pm = pm_env >= 0 ? pm_env : (ut.n_ids <= 2 * device_cus() ? 1 : 0);
-    dim3 grid(pm ? pm_grid(ut.n_ids, TBm * (TBm + 1) / 2) : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
+    // (round 4: deeper launches part by part too, in GROUPS of 64 launch slots — a unit's workgroups then run within one L2
+    // residency window and longest first inside the group: C4 762 -> 738 us; launch-wide groups there were the 809)
+    const bool deep = ut.n_ids > 2 * device_cus();
+    const int pm = pm_env >= 0 ? pm_env : 1;
+    const int G = pm_group() > 0 ? pm_group() : (deep ? 64 : 0);
+    dim3 grid(pm ? (G > 0 ? ((ut.n_ids + G - 1) / G) * G * (TBm * (TBm + 1) / 2) : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2))
+                 : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
     UnitTab utp = ut;
-    utp.pm_group = pm_group();
+    utp.pm_group = G;
     if (dist_id == 0 && kern_id == 0) {
         // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
         int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;

@@ -64,6 +64,8 @@ def test_single_launch_table_build_with_many_blocks(tmp_path):
     shape = {"VAR_N": "4000", "VAR_BLOCKS": "400"}
     base = run_variant(tmp_path, shape)
     assert run_variant(tmp_path, dict(shape, GPRF_FUSED_BUILD="0")) == base
+    # a launch more than two rounds of CUs deep: the gradient grid is walked part by part in groups of 64 launch slots
+    assert run_variant(tmp_path, dict(shape, GPRF_PART_MAJOR="0")) == base
 
 
 def test_launch_variants_agree_bit_for_bit(tmp_path):
