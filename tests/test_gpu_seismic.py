@@ -158,3 +158,32 @@ def test_config5_block_size_lld_matern32_units_above_256_points():
     assert np.max(np.abs(a[1] - b[1])) <= 1e-9 * np.max(np.abs(b[1]))
     assert np.allclose(a[2], b[2], rtol=1e-8)
     g.close()
+
+
+def test_far_apart_events_take_the_closed_form_great_circle_branch():
+    """The lld kernel evaluates the great-circle terms by polynomials in the haversine for pairs closer than 2560 km and in
+    closed form (asin, square roots) beyond: events scattered over the whole globe in two blocks and their pair — most pairs
+    are far apart, some close, a few nearly antipodal — against the oracle (numpy's arcsin), values and both gradients."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(12)
+    n = 140
+    X = np.column_stack([rng.uniform(-180.0, 180.0, n), rng.uniform(-75.0, 75.0, n), rng.uniform(0.0, 120.0, n)])
+    X[5] = [X[4, 0] + 0.3, X[4, 1] - 0.2, X[4, 2] + 3.0]                 # a close pair
+    # a nearly antipodal one, half a degree off (AT the antipode the haversine itself is ill-conditioned — dg/da = R / sqrt(a (1 - a))
+    # — and two correct evaluations differ by 1e-8 in k: measured, 6e-11 in ll)
+    X[7] = [((X[6, 0] + 360.0) % 360.0) - 180.0 + 0.5, -X[6, 1] + 0.4, X[6, 2]]
+    Y = rng.randn(n, 6)
+    blocks = [np.arange(0, 70), np.arange(70, n)]
+    nbrs = [(0, 1)]
+    ls = [9000.0, 150.0]
+    g = GPRF(X, Y, None, GPCov([1.3], ls, "lld", "matern32"), 0.2, block_idxs=blocks, neighbors=nbrs)
+    r = GPRFRef(X, Y, None, OC([1.3], ls, "lld", "matern32"), 0.2, block_idxs=blocks, neighbors=nbrs)
+    a = g.llgrad(grad_X=True, grad_cov=True)
+    b = r.llgrad(grad_X=True, grad_cov=True)
+    g.close()
+    assert np.isclose(a[0], b[0], rtol=1e-11)
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-9 * np.max(np.abs(b[1]))
+    assert np.allclose(a[2], b[2], rtol=1e-8, atol=1e-9 * np.abs(b[2]).max())
