@@ -124,6 +124,30 @@ def test_jitter_path_matches_jitchol():
     g.close()
 
 
+@pytest.mark.parametrize("m", [300, 400])
+def test_not_pd_is_reported_by_the_wide_register_cholesky(m):
+    """A unit of 19 / 25 tiles per edge with a duplicated point and zero noise: the eight-wave register kernel (its overflow
+    tiles waiting in LDS / in the U pool) reports the failed pivot like every other Cholesky kernel; with the jitter schedule
+    the evaluation goes through and matches the oracle's jitchol path (cond ~ 1e6: rtol 1e-6)."""
+    from gprf_amd.gprf import GPRF
+    from gprf_amd import GPCov, _capi
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(m)
+    X = rng.rand(m, 2)
+    X[m - 7] = X[m - 40]                           # the duplicate sits in the last tiles: the failure comes late in the chain
+    Y = rng.randn(m, 4)
+    g = GPRF(X, Y, None, GPCov([1.0], [0.3, 0.3], "euclidean", "se"), 0.0, block_idxs=[np.arange(m)], neighbors=[])
+    rc, _, _, _, bad = g._ctx.eval(X, True, True)
+    assert rc == _capi.GPRF_NOT_PD and bad == 0
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    r = GPRFRef(X, Y, None, OC([1.0], [0.3, 0.3], "euclidean", "se"), 0.0, block_idxs=[np.arange(m)], neighbors=[])
+    o = r.llgrad(grad_X=True, grad_cov=True)
+    assert g._jitter[0] > 0.0
+    assert np.isclose(ll, o[0], rtol=1e-5)
+    g.close()
+
+
 def test_not_pd_even_with_jitter_raises():
     from gprf_amd.gprf import GPRF
     from gprf_amd import GPCov
