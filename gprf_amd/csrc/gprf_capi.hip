@@ -128,6 +128,7 @@ struct gprf_ctx {
     DevBuf<int32_t> d_big_list, d_small_list;
     DevBuf<SlotRec> d_srec, d_big_rec, d_small_rec;
     int grid_big = 0, grid_small = 0;     // launch sizes of the Cholesky's two lists (list lengths at the last sync + slack)
+    int n_wide = 0;                       // local units of more than 20 tiles per edge at the last sync (potrf_generates_K)
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
@@ -260,6 +261,7 @@ UnitTab make_tab(gprf_ctx *c) {
     t.grid_big = c->grid_big; t.grid_small = c->grid_small;
     t.fork_flag = nullptr; t.fork_seq = 0;
     t.pm_group = 0;
+    t.n_wide = c->n_wide;
     return t;
 }
 
@@ -320,8 +322,12 @@ void refresh_host_units(gprf_ctx *c) {
     c->cur_rows = rows; c->cur_mat = mat;
     c->work_flops = flops; c->work_fill_bytes = fbytes;
     // launch sizes of the Cholesky's two lists: the present lengths + slack, followed down only when far above
-    int nbig = 0;
-    for (int l = 0; l < nl; ++l) nbig += pad16(c->l_m[l]) / 16 > potrf_small_maxT() ? 1 : 0;
+    int nbig = 0, nwide = 0;
+    for (int l = 0; l < nl; ++l) {
+        nbig += pad16(c->l_m[l]) / 16 > potrf_small_maxT() ? 1 : 0;
+        nwide += pad16(c->l_m[l]) / 16 > 20 ? 1 : 0;      // units the generating Cholesky kernels do not take
+    }
+    c->n_wide = nwide;
     // (surplus workgroups of the large-unit launch take small units, see potrf_reg_body: slack costs nothing there; the
     // small-unit launch simply covers every unit)
     if (nbig + 8 > c->grid_big || nbig + 96 < c->grid_big) c->grid_big = std::min(nl, nbig + 32);

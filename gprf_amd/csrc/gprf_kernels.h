@@ -55,6 +55,7 @@ struct UnitTab {
     const int32_t *ctl;
     int grid_big, grid_small;   // workgroups the two lists are launched with (the build reports a list that is longer)
     int pm_group;               // part-major grids (solve, gradient): group size of the walk, 0 = launch-wide (part_major_map)
+    int n_wide;                 // units of more than 20 tiles per edge at the last synchronised partition (potrf_generates_K)
     // fork of the two Cholesky queues: the first workgroup of the large-unit kernel stores fork_seq here as its first
     // instruction; the side queue's small-unit kernel sits behind a stream wait for that value (nullptr: none)
     uint32_t *fork_flag;

@@ -4210,7 +4210,10 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     // every unit of up to 28 tiles (waiting tiles in the U pool) — behind the generating kernels it would run by itself, a
     // unit's whole chain later (measured, 49 blocks of ~184 points + 156 pairs of 20-27 tiles: fill + Cholesky 32 + 281 us
     // against 28 + 439)
-    if (ut.max_T > 20 && potrf_gw()) return false;
+    // — when such units are MANY (an eighth of the launch, at least 16).  A few (one pair of a north-star-shaped partition
+    // growing past 320 points) leave the others generated, as round 2 decided per unit: they are filled, and take the
+    // eight-wave kernel (up to 28 tiles) or the generic one behind the generating kernels.
+    if (ut.max_T > 20 && potrf_gw() && ut.n_wide >= 16 && 8 * ut.n_wide >= ut.n_ids) return false;
     return !off && (se || lld) && ut.n_ids > 0 && potrf_use_reg(ut);
 }
 constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
@@ -4335,6 +4338,13 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
     auto launch_generic = [&]() {
         if (ut.max_T <= reg_maxT) return;
+        // the few units of 21 .. 28 tiles per edge of a generating launch: the eight-wave kernel with its waiting tiles in the
+        // U pool, from the K pool (they were filled), behind the generating kernels; the generic kernel above that
+        if (gen && wide && dk == 0 && potrf_gw() && reg_maxT == POTRF_REG8_MAXT) {
+            launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, POTRF_REG8_MAXT + 1);
+            reg_maxT = POTRF_REG8W_MAXT;
+            if (ut.max_T <= reg_maxT) return;
+        }
 
         const int capG = ut.max_T < SMALL_MAX_T ? ut.max_T : SMALL_MAX_T;      // (larger units: launch_big_potrf)
         size_t ldsg = (size_t)(16 * (16 * capG + 16) + 256 + 16 + 16 * 17 + 256 + 16 * capG) * sizeof(double);

@@ -151,6 +151,50 @@ def test_units_of_21_to_28_tiles_wait_in_the_U_pool(tmp_path):
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
 
 
+FEW_WIDE_DRIVER = r'''
+import sys
+import numpy as np
+from gprf_amd import Blocker, grid_centers, GPCov
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(5)
+n = 2200
+X = rng.rand(n, 2)
+c = np.array(grid_centers(25))
+X[:230] = c[12] + 0.06 * (rng.rand(230, 2) - 0.5)          # the centre block crowded: its eight pairs exceed 320 points
+Y = rng.randn(n, 5)
+b = Blocker(c)
+g = GPRF(X, Y, b.block_clusters, GPCov([1.0], [0.09, 0.11], "euclidean", "se"), 0.02, neighbors=b.neighbors())
+sz = [len(u) for u in g.block_idxs]
+tiles = [(sz[i] + sz[j] + 15) // 16 for i, j in g.neighbors]
+wide = [t for t in tiles if t > 20]
+assert 4 <= len(wide) < 16 and max(wide) <= 28 and min(tiles) <= 13, sorted(tiles)
+ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
+g.close()
+'''
+
+
+def test_a_few_wide_units_leave_the_others_generated(tmp_path):
+    """A north-star-shaped partition with ONE crowded block: its eight pairs have 21-28 tiles per edge, everything else at most
+    13.  The launch stays a generating one (round 2's per-unit decision): the wide pairs are filled and take the eight-wave
+    kernel with waiting tiles in the U pool BEHIND the generating kernels (GPRF_POTRF_GW=0: the generic kernel) — the same
+    bits as everything through the pool"""
+    import numpy as np
+    (tmp_path / "few.py").write_text(FEW_WIDE_DRIVER)
+    out = {}
+    for tag, env in (("gen", {}), ("generic", {"GPRF_POTRF_GW": "0"}), ("pool", {"GPRF_FUSED_FILL": "0"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        e.update(env)
+        r = subprocess.run([sys.executable, str(tmp_path / "few.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        out[tag] = np.load(str(tmp_path / (tag + ".npz")))
+    a = out["gen"]
+    for tag in ("generic", "pool"):
+        b = out[tag]
+        assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
+
+
 def test_se_fill_forms_and_grouped_walk_agree_bit_for_bit(tmp_path):
     """K through the pool (GPRF_FUSED_FILL=0): k_fill_se (half the vector-ALU instructions per value) against the
     entry-by-entry k_fill<0,0>; and the solve / gradient grids walked part by part in groups of 64 launch slots against
