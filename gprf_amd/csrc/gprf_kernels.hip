@@ -1259,20 +1259,26 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // n_lds: tiles beyond ALL RW * SLOTS accumulator slots (the eight-wave kernel, T = 19, 20): the first n_lds tiles in
     // row-major order stay in LDS (Ot) — solved from there when their row comes up, updated there until then; the others
     // (real index n_lds + idx) are dealt as before
+    // FRONT (round 4, the eight-wave kernel too): stamps on a 20-tile unit — wave 0, dealt every eighth tile of ALL rows, spent
+    // 12.8 k cycles per step in its phase (7.5 k of chain + its share of every trailing update) and the workers 5.7 k of their
+    // 15.6 k waiting for it; with its 20 tiles front-loaded (the rows right behind the waiting tiles) it is a pure factor wave
+    // from step 3 on: the seismic shape's Cholesky stage 146 -> 134 us, at paper scale 1464 -> 1413.  (Units of up to 17 tiles have
+    // no such tiles: nothing changes for them.  The four-wave two-per-CU kernel front-loaded: C3 109.2 -> 110, C4 662 -> 670: no.)
+    constexpr bool FRONT = RA || RW == 8;
     const int total_all = T * (T - 1) / 2;
     const int n_lds = (RW == 8 && total_all > RW * SLOTS) ? total_all - RW * SLOTS : 0;      // (RW == 4: a constant 0)
     const int total = total_all - n_lds;
     const int ov = total > NW * SLOTS ? total - NW * SLOTS : 0;      // (a larger share for wave 0 — total / 6 .. / 14 — measured: no change)
-    const int head = RA ? ov : (RW * ov < total ? RW * ov : total);
+    const int head = FRONT ? ov : (RW * ov < total ? RW * ov : total);
     const bool w0busy = ov > 0;                        // wave 0 owns tiles too
     const bool mine = wave > 0 || w0busy;
     const int wpos = wave == 0 ? NW : wave - 1;        // position in the RW-way deal; workers: also in the NW-way
-    const int nhead = RA ? (wave == 0 ? ov : 0)
+    const int nhead = FRONT ? (wave == 0 ? ov : 0)
                          : (head - wpos + NW < 0 ? 0 : (head - wpos + NW) / RW);      // this wave's tiles of the RW-way part
     // tiles of this wave among idx < r
     auto cnt = [&](int r_all) {
         const int r = r_all > n_lds ? r_all - n_lds : 0;      // (row boundaries come as real tile indices)
-        if constexpr (RA) {
+        if constexpr (FRONT) {
             if (wave == 0) return r < ov ? r : ov;
             int c = r - ov - wpos + NW - 1;
             return (r <= ov || c < 0) ? 0 : c / NW;
@@ -1291,7 +1297,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     int pkv = -1, shv = 0;
     {
         int sl = lane;
-        int idx = RA ? (wave == 0 ? (sl < ov ? sl : total) : ov + NW * sl + wpos)
+        int idx = FRONT ? (wave == 0 ? (sl < ov ? sl : total) : ov + NW * sl + wpos)
                      : (sl < nhead ? RW * sl + wpos : (wave == 0 ? total : head + NW * (sl - nhead) + wpos));
         int i = 0, rs = 0, rl = T - 1;
         const int idr = idx + n_lds;                    // the tile's real row-major index

@@ -10,6 +10,7 @@ X = seismic.synthetic_events(n, seed=0)
 Y = np.random.RandomState(1).randn(n, 50)
 blocks, reblock = seismic.pdtree_cluster(X, 210)
 g = GPRF(X, Y, reblock, GPCov([1.0], [40.0, 40.0], "lld", "matern32"), 0.1, neighbor_threshold=0.6)
+g._push_neighbors(g.neighbors)
 ctx = g._ctx
 for _ in range(3): ctx.debug_run(X, 6)
 nt, nl = ctx.num_units()
