@@ -2197,7 +2197,12 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 #ifdef GPRF_PROFILE
     unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (!(PM ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, ut.pm_group, &slot_, &part_) : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
+    // (PM instantiations: a negative group size selects the unit-major walk at run time — the large instantiations exist once,
+    // their compile time is minutes; the small hot ones keep the walk a template parameter: as a run-time field the same
+    // kernel was 5 % slower)
+    if (!(PM ? (ut.pm_group >= 0 ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, ut.pm_group, &slot_, &part_)
+                                 : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))
+             : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
     // the Y workgroup (every step, a gather in front) is the longest of a unit: it is dispatched first
     part_ = part_ == 0 ? nI : part_ - 1;
     const UnitRef ur = unit_ref(ut.srec, slot_);
@@ -4501,6 +4506,9 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
     // PM: the grid walked part by part (part_major_map) — launches several rounds deep; GPRF_PART_MAJOR=0 / 1 forces
     static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool pm = pm_env >= 0 ? pm_env == 1 : ut.n_ids <= 2 * device_cus();
+    // (GPRF_ONLY_POTRF: tests/test_isa_invariants.py compiles this file for the Cholesky kernels' ISA alone — the dozen
+    // unrolled k_solve_panel / k_mgrad instantiations are two thirds of the compile time)
+#ifndef GPRF_ONLY_POTRF
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
         const int nparts = (ut.max_T + 3) / 4 + 1;
         dim3 grid(pm ? pm_grid(ut.n_ids, nparts) : xcd_grid(ut.n_ids, nparts));
@@ -4520,18 +4528,20 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
             // each as the accumulators of 20 tiles need — the seismic configuration's pairs of 312 points)
             if (pm) hipLaunchKernelGGL((k_solve_panel<20, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<20, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        } else if (ut.max_T <= 26) {      // (one panel buffer, two workgroups per CU: the paper-scale catalogue's pairs of 390 points)
-            if (pm) hipLaunchKernelGGL((k_solve_panel<26, 2, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
-            else hipLaunchKernelGGL((k_solve_panel<26, 2, false, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        } else if (ut.max_T <= 28) {      // (448 points cover the seismic configuration's pairs at every block size below 210)
-            if (pm) hipLaunchKernelGGL((k_solve_panel<28, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
-            else hipLaunchKernelGGL((k_solve_panel<28, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else {
-            if (pm) hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
-            else hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+            // the large instantiations exist once each (the walk chosen at run time: see the kernel)
+            if (!pm) utp.pm_group = -1;
+            if (ut.max_T <= 26)           // (one panel buffer, two workgroups per CU: the paper-scale catalogue's pairs of 390 points)
+                hipLaunchKernelGGL((k_solve_panel<26, 2, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else if (ut.max_T <= 28)      // (448 points: the seismic configuration's pairs at every block size below 210; 11 % faster
+                                          // there than the 32-tile instantiation)
+                hipLaunchKernelGGL((k_solve_panel<28, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
+            else                          // (units of up to 512 points, one workgroup per CU)
+                hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
         }
         return;
     }
+#endif
     // units of more than 512 points: accumulators no longer fit the register budget -> LDS-broadcast form
     // (its grid covers units of up to 1024 points; larger ones are skipped here: launch_big_solve)
     UnitTab uts = ut;
@@ -4565,6 +4575,7 @@ void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, in
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,
                  bool have_K, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
+#ifndef GPRF_ONLY_POTRF
     int TBm = (ut.max_T + 3) / 4;
     static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // (only while the launch is a few rounds deep: with thousands of units the ten workgroups of a unit would run far apart
@@ -4594,6 +4605,7 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     } else {
         hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

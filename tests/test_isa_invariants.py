@@ -18,7 +18,9 @@ def isa(tmp_path_factory):
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("hipcc not available")
     out = str(tmp_path_factory.mktemp("isa") / "gprf_kernels.s")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+    # (-DGPRF_ONLY_POTRF: the Cholesky kernels alone — the unrolled k_solve_panel / k_mgrad instantiations are two thirds of
+    # the file's compile time and nothing here looks at them)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DGPRF_ONLY_POTRF",
                            "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",       # as gprf_amd/build.py
                            "-o", out, SRC], stderr=subprocess.DEVNULL)
     return open(out).read().split("\n")
