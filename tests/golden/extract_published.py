@@ -26,6 +26,11 @@ RUNS = [
 ]
 
 
+# runs kept in FULL (round 5: every line, for the run-to-convergence comparison of tests/test_gpu_trace_full.py); the others
+# keep their first six lines
+FULL = {r for r in RUNS if r.startswith("2000_2500_") or r.startswith("10000_10500_100_")}
+
+
 def main():
     out = {}
     with tarfile.open(TGZ) as tf:
@@ -34,7 +39,7 @@ def main():
             assert len(member) == 1, run
             lines = io.TextIOWrapper(tf.extractfile(member[0])).read().strip().split("\n")
             rec = {"steps": []}
-            for ln in lines[:6]:
+            for ln in (lines if run in FULL else lines[:6]):
                 f = ln.split()
                 if f[0] == "trueX":
                     continue
@@ -43,6 +48,8 @@ def main():
             tx = [ln.split() for ln in lines if ln.startswith("trueX")]
             if tx:
                 rec["trueX_objective"] = tx[0][2]
+            rec["n_lines"] = len([ln for ln in lines if not ln.startswith("trueX")])
+            rec["total_secs"] = max(float(ln.split()[1]) for ln in lines if not ln.startswith("trueX"))
             secs = [float(ln.split()[1]) for ln in lines if not ln.startswith("trueX")]
             d = sorted(b - a for a, b in zip(secs[:-1], secs[1:]))
             rec["median_secs_per_eval"] = d[len(d) // 2] if d else None

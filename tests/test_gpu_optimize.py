@@ -48,6 +48,7 @@ def test_lbfgs_reproduces_published_trace(published, local_dist, nblocks):
     sd = SampledData(n=ntrain + 500, ntrain=ntrain, lscale=6 / np.sqrt(ntrain), obs_std=2 / np.sqrt(ntrain), yd=50, seed=0)
     sd.set_centers(grid_centers(nblocks))
     rec = published["2000_2500_%d_0.134164_0.044721_%s_50_l-bfgs-b_x_-1_0.0100_s0_gprf0" % (nblocks, "%.4f" % local_dist)]
+    steps = rec["steps"][:6]          # (the whole trace, run to convergence: tests/test_gpu_trace_full.py)
     g = sd.build_gprf(local_dist=local_dist)
     obj = Objective(g, sd.X_obs, None, sd)
     xs = []
@@ -58,15 +59,15 @@ def test_lbfgs_reproduces_published_trace(published, local_dist, nblocks):
     def f(x):
         xs.append(x.copy())
         v = obj(x)
-        if len(xs) >= len(rec["steps"]):
+        if len(xs) >= len(steps):
             raise _Stop
         return v
     try:
         scipy.optimize.minimize(f, obj.full0, jac=True, method="l-bfgs-b", options={"ftol": 1e-6, "maxiter": 200})
     except _Stop:
         pass
-    assert len(xs) == len(rec["steps"])
-    for k, step in enumerate(rec["steps"]):
+    assert len(xs) == len(steps)
+    for k, step in enumerate(steps):
         assert "%.2f" % obj.trace[k][2] == step["objective"], (k, obj.trace[k][2], step["objective"])
         err = np.mean(np.sqrt(np.sum((xs[k].reshape(-1, 2) - sd.SX) ** 2, axis=1)))
         assert "%.8f" % err == step["mean_loc_err"]
