@@ -44,6 +44,19 @@ FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profi
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 STAGE_PASS_EVALS = 60     # evaluations of the separate pass that times every kernel of every evaluation
+
+
+def _fill_counter_gbps():
+    """(WRITE_SIZE + 2 FETCH_SIZE) per launch / the kernel's average duration, from the committed rocprofv3 passes of k_fill_se
+    (scripts/profile_fill.sh -> profiles/r05_fill_counters.json); None when they were never taken"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_fill_counters.json")) as f:
+            return float(json.load(f)["counter_GBps"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+FILL_COUNTER_GBPS = _fill_counter_gbps()
 REPS = 7                  # repetitions of the timed loop; `value` is their median (a slow leg shows in the samples, not in the headline)
 
 
@@ -224,7 +237,7 @@ def git_head():
 def _last_json_line(text):
     for line in reversed(text.splitlines()):
         line = line.strip()
-        if line.startswith("{") and '"metric"' in line:
+        if line.startswith("{") and ('"metric"' in line or '"value"' in line):      # (the --no-stage-timing line has no "metric")
             try:
                 return json.loads(line)
             except ValueError:
@@ -248,10 +261,21 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), me] + argv
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    # (bounded: a stuck rendezvous or collective initialisation must not hang whoever called this for good)
+    limit = float(os.environ.get("GPRF_BENCH_CHILD_TIMEOUT_S", "3000"))
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
+    except subprocess.TimeoutExpired as e:
+        def _txt(b):
+            return b.decode(errors="replace") if isinstance(b, bytes) else (b or "")
+        sys.stderr.write("bench.py: the %d-rank child did not finish within %.0f s\n--- its stdout (tail)\n%s\n--- its stderr (tail)\n%s\n"
+                         % (args.gpus, limit, _txt(e.stdout)[-2000:], _txt(e.stderr)[-4000:]))
+        sys.exit(124)
     line = _last_json_line(r.stdout or "")
     if r.returncode != 0 or line is None:
         sys.stdout.write(r.stdout or "")
+        sys.stderr.write("bench.py: the %d-rank child exited with code %d%s\n--- its stderr (tail)\n%s\n"
+                         % (args.gpus, r.returncode, "" if line is not None else " and printed no result line", (r.stderr or "")[-4000:]))
         sys.exit(r.returncode if r.returncode != 0 else 1)
     line["launched_by"] = "bench.py itself: child `python -m torch.distributed.run --nproc-per-node %d` (%.0f s)" % (
         args.gpus, time.perf_counter() - t0)
@@ -579,20 +603,27 @@ def main():
         result["device_resident_evals_per_s"] = args.steps / (time.perf_counter() - t1)
         # K is generated inside k_potrf_reg on this configuration and k_fill does not run; the fill kernel's HBM
         # write rate is measured on the side by forcing the K pool back for a few evaluations
-        os.environ["GPRF_FUSED_FILL"] = "0"
+        # (gprf_debug_run with stop_after = 0: gather + the fill of EVERY unit, nothing else)
         e = evs[0]
         e.g._ctx.set_timing(True, reset=True)
         for _ in range(8):
-            e.enqueue(True, grad_cov, stream=run_stream)
+            e.g._ctx.debug_run(Xlist[0], 0)
         torch.cuda.synchronize()
         tmf = e.g._ctx.get_timing()
         e.g._ctx.set_timing(False, reset=True)
-        del os.environ["GPRF_FUSED_FILL"]
         f0 = algorithmic_flops(sizes_all[0], args.yd)
+        # bytes k_fill_se really writes: the 64 x 64 blocks ti <= tj of every unit (diagonal blocks whole)
+        written = 0.0
+        for mp_ in (sizes_all[0] + 15) // 16 * 16:
+            r0 = np.arange(0, mp_, 64)
+            written += 8.0 * float(np.sum(np.minimum(64, mp_ - r0) * (mp_ - r0)))
         result["roofline"]["fill_kernel"] = {
-            "GBps": f0["fill_bytes"] / (tmf["fill"] * 1e-3) / 1e9, "ms": tmf["fill"], "potrf_ms_reading_K": tmf["potrf"],
-            "note": "k_fill timed with GPRF_FUSED_FILL=0; by default k_potrf_reg generates K and it never exists in HBM "
-                    "(stages_ms.fill is then two event records)"}
+            "GBps": f0["fill_bytes"] / (tmf["fill"] * 1e-3) / 1e9, "written_GBps": written / (tmf["fill"] * 1e-3) / 1e9,
+            "ms": tmf["fill"], "counter_GBps": FILL_COUNTER_GBPS,
+            "note": "k_fill_se timed through the library's fill-only debug run; by default k_potrf_reg generates K and it never "
+                    "exists in HBM (stages_ms.fill is then two event records).  GBps = algorithmic 8 m^2 per unit; written_GBps = "
+                    "the 64-row block rows from their diagonal block to the unit's edge, which is what it stores; counter_GBps = (WRITE_SIZE + FETCH_SIZE) / duration from the committed "
+                    "rocprofv3 pass of this kernel (profiles/r05_fill_rocprof_summary.txt), null until taken"}
         for ev in evs:
             ev.g.close()
         # BASELINE configs[1]: no pairs
@@ -617,6 +648,28 @@ def main():
             gb.close()
         sd.set_centers(grid_centers(args.nblocks))
         result["big_units"] = big
+
+    # ---------------- time to solution: the reference's whole optimisation run on the north-star data (gprfopt.py:377-432:
+    # scipy L-BFGS-B, ftol 1e-6, maxiter 200, task x) — outside the timed region; how much of an evaluation's wall time is
+    # the device and how much scipy's host loop around 20000 variables
+    if n_members == 1 and rank == 0 and not args.only_north_star and args.ntrain == 10000 and args.task == "x":
+        from gprf_amd.objective import do_optimization
+        go = sd.build_gprf(local_dist=args.local_dist, device=local_rank)
+        do_optimization(go, sd.X_obs, None, sd, maxsec=None, maxiter=3)      # (warm: workspace, instantiations)
+        t0 = time.perf_counter()
+        z_fin, ob = do_optimization(go, sd.X_obs, None, sd, maxsec=None, maxiter=200)
+        wall = time.perf_counter() - t0
+        n_ev = len(ob.trace)
+        err = float(np.mean(np.sqrt(np.sum((z_fin.reshape(-1, 2) - sd.SX) ** 2, axis=1))))
+        result["optimize_c3"] = {
+            "evals": n_ev, "wall_s": wall, "ms_per_eval_wall": 1e3 * wall / n_ev, "gpu_ms_per_eval": result["ms_per_step"],
+            "host_ms_per_eval": 1e3 * wall / n_ev - result["ms_per_step"],
+            "first_objective": ob.trace[0][2], "final_objective": ob.trace[-1][2], "final_mean_location_error": err,
+            "reference_published": {"evals": 89, "wall_s": 650.03, "first_objective": -6563678.10,
+                                    "final_objective": 409688.60, "final_mean_location_error": 0.00363347,
+                                    "run": "10000_10500_100_0.060000_0.020000_0.1000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0"},
+            "note": "scipy.optimize L-BFGS-B (ftol 1e-6, maxiter 200) driving gprf_objective; host = scipy's own loop + Python"}
+        go.close()
 
     # ---------------- BASELINE configs[3] (n=80000, 841 blocks + 3192 pairs, task xcov), same sequential loop, every N
     if not args.only_north_star and not args.no_c4 and args.ntrain == 10000:

@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
         try:
             if not force and not _stale():      # somebody else built it while this process waited
                 return LIB
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
@@ -48,21 +48,36 @@ def _flags():
     return os.environ.get("GPRF_BUILD_DEFS", "").split() + flags
 
 
-def _build_locked(verbose):
-    """One object per source (kept under csrc/_obj next to a stamp of the flags and the headers' times: a change to the
-    host layer alone does not recompile the kernels' 90 seconds), then one link."""
+def _compiler_id(hipcc):
+    """what the object cache is keyed on besides the flags: another hipcc / ROCm must not reuse old objects"""
+    try:
+        return subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout.decode()
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
+
+
+def _build_locked(verbose, force=False):
+    """One object per source (kept under csrc/_obj, named by a hash of the flags, the library name and the compiler's
+    version: a change to the host layer alone does not recompile the kernels' two minutes), then one link.  ``force``
+    recompiles everything; objects of other flag sets (diagnostic builds) older than a week are removed."""
     import hashlib
+    import time
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = _flags()
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
-    tag = hashlib.sha256((" ".join(flags) + os.path.basename(LIB)).encode()).hexdigest()[:12]
+    tag = hashlib.sha256((" ".join(flags) + os.path.basename(LIB) + _compiler_id(hipcc)).encode()).hexdigest()[:12]
+    for old in os.listdir(objdir):
+        path = os.path.join(objdir, old)
+        if old.endswith(".o") and ("." + tag + ".") not in old and time.time() - os.path.getmtime(path) > 7 * 86400:
+            os.remove(path)
     objs = []
     for f in SOURCES:
         src = os.path.join(CSRC, f)
         obj = os.path.join(objdir, "%s.%s.o" % (os.path.splitext(f)[0], tag))
-        if not (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t)):
+        # (>=: a header touched within the same clock tick as the object counts as newer)
+        if force or not (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t)):
             cmd = [hipcc] + flags + ["-c", "-o", obj + ".tmp.%d" % os.getpid(), src]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -89,4 +104,5 @@ def _build_locked(verbose):
 
 if __name__ == "__main__":
     import sys
-    print(build(force=True, verbose="-v" in sys.argv))
+    # `python -m gprf_amd.build`: build if stale; `--force`: recompile every source whatever the object cache says
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

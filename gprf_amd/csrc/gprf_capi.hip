@@ -232,11 +232,10 @@ int create_fail(int code, const std::string &msg) {
 
 inline int pad16(int m) { return (m + 15) & ~15; }
 
-// the largest unit accepted: GPRF_MAX_UNIT, or less through GPRF_MAX_UNIT_OVERRIDE (tests of the refusal path: a unit of
+// the largest unit accepted: GPRF_MAX_UNIT, or less through GPRF_DIAG max_unit=<points> (tests of the refusal path: a unit of
 // 16385 points costs 4e12 flop to get to)
 int max_unit_limit() {
-    const char *e = getenv("GPRF_MAX_UNIT_OVERRIDE");
-    int v = e ? atoi(e) : 0;
+    int v = diag("max_unit", 0);
     return (v > 0 && v < GPRF_MAX_UNIT) ? v : GPRF_MAX_UNIT;
 }
 
@@ -273,7 +272,7 @@ BuildTab make_build(gprf_ctx *c) {
     b.ids = c->d_ids.p; b.big_list = c->d_big_list.p; b.small_list = c->d_small_list.p;
     b.srec = c->d_srec.p; b.big_rec = c->d_big_rec.p; b.small_rec = c->d_small_rec.p;
     b.pe = c->d_pe.p; b.ebase = c->d_ebase.p; b.einfo = c->d_einfo.p;
-    b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE && potrf_dual_enabled()) ? potrf_small_maxT() : 0;
+    b.small_maxT = (c->dist_id == GPRF_DIST_EUCLIDEAN && c->kern_id == GPRF_KERN_SE) ? potrf_small_maxT() : 0;
     b.grid_big = c->grid_big; b.grid_small = c->grid_small;
     b.m = c->d_m.p; b.row_off = c->d_rowoff.p; b.mat_off = c->d_matoff.p; b.off_j = c->d_offj.p; b.upt = c->d_upt.p;
     b.Xu = c->d_Xu.p; b.xstride = c->dist_id == GPRF_DIST_LLD ? 8 : XPAD;
@@ -703,7 +702,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         side.s2 = c->stream2; side.ev_fork = c->ev_fork; side.ev_join = c->ev_join;
         side.words = c->side_values ? c->d_side.p : nullptr;
         side.seq = ++c->side_seq;
-        launch_potrf(ut, pl, kp, gen, c->dist_id == 1 ? 1 : 0, s, side);
+        launch_potrf(ut, pl, kp, gen, s, side);
         launch_big_potrf(ut, pl, kp, s);
     }
     mark();
@@ -719,8 +718,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         // k_gx_finalize is a launch of its own for sums the assembly can do on the way (10 us of a 430 us evaluation) —
         // up to GX_FOLD_MAX_UNITS units; beyond that the assembly's single summing workgroup would walk every unit's
         // partials itself (C4: 106 us against 20).  The per-unit gradient (gprf_debug_fetch) is then made on demand.
-        static const bool fold_on = [] { const char *e = getenv("GPRF_GX_FOLD"); return !(e && e[0] == '0'); }();
-        fold_gx = fold_on && stop_after >= 5 && c->n_local <= GX_FOLD_MAX_UNITS;
+        fold_gx = diag("gx_fold", 1) != 0 && stop_after >= 5 && c->n_local <= GX_FOLD_MAX_UNITS;
         if (!fold_gx) launch_gx_finalize(ut, pl, kp, want_gc, s);
         c->gxu_pending = fold_gx;
         c->gxu_want_gc = want_gc;
@@ -1112,7 +1110,7 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
     {
         int can = 0;
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
-        if (const char *e = getenv("GPRF_SIDE_EVENTS")) { if (e[0] == '1') can = 0; }      // diagnostics: force events
+        if (diag("side_events", 0)) can = 0;      // diagnostics: force events
         if (can && c->d_side.reserve(16, 1.0) == hipSuccess && hipMemset(c->d_side.p, 0, 16 * sizeof(uint32_t)) == hipSuccess)
             c->side_values = true;
     }
@@ -1242,9 +1240,9 @@ int gprf_group_info(const gprf_ctx *c, int32_t *n_members, int32_t *slots_on_hos
 
 const char *gprf_runtime_config(void) {
     static thread_local char buf[256];
-    const char *io = getenv("GPRF_IO_MODE"), *sy = getenv("GPRF_SYNC");
-    snprintf(buf, sizeof buf, "side_mode=%d tool_env=%d potrf_dual=%d io_mode=%d sync=%s", potrf_side_mode(), potrf_tool_env() ? 1 : 0,
-             potrf_dual_enabled() ? 1 : 0, (io && (io[0] == '1' || io[0] == '2')) ? io[0] - '0' : 0, (sy && sy[0] == 'b') ? "block" : "poll");
+    const char *io = getenv("GPRF_IO_MODE"), *sy = getenv("GPRF_SYNC"), *dg = getenv("GPRF_DIAG");
+    snprintf(buf, sizeof buf, "side_mode=%d tool_env=%d io_mode=%d sync=%s diag=%.120s", potrf_side_mode(), potrf_tool_env() ? 1 : 0,
+             (io && (io[0] == '1' || io[0] == '2')) ? io[0] - '0' : 0, (sy && sy[0] == 'b') ? "block" : "poll", dg ? dg : "");
     return buf;
 }
 

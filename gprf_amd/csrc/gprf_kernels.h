@@ -190,10 +190,10 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
 // whether the register-resident Cholesky generates the kernel matrices of its units (at most potrf_gen_maxT() tiles per
 // edge) itself; larger units are filled into the K pool and factored by the generic kernel
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
-int potrf_gen_maxT(int dist_id);   // (20 on the SE path with its two instantiations, 16 otherwise)
-bool potrf_dual_enabled();      // the register-resident Cholesky runs as two instantiations side by side ...
-int potrf_small_maxT();         // ... units of at most this many tiles per edge two to a CU
-bool potrf_run_ahead();         // the register Cholesky without workgroup barriers in its step loop (GPRF_POTRF_RA=0: with)
+int potrf_gen_maxT(int dist_id);   // (20)
+int potrf_small_maxT();         // the register-resident Cholesky runs as two instantiations side by side: units of at most this
+                                // many tiles per edge two to a CU
+int diag(const char *key, int dflt);   // GPRF_DIAG="key=value,...": the one diagnostic switch (gprf_kernels.hip)
 int potrf_side_mode();          // how the two queues fork / join (launch_potrf): 4 = kernel-written fork word + memory-op join, 0 = events
 bool potrf_tool_env();          // a profiler / serialising launch mode is in the environment
 // The second queue for the instantiation that runs beside the main one, and how the two queues wait for each other:
@@ -205,8 +205,8 @@ struct SideQueue {
     uint32_t *words = nullptr;      // [3] device words: fork, join, fork written by the large-unit kernel itself
     uint32_t seq = 0;               // value of this evaluation (monotonic)
 };
-// dk (gen only): 0 = SE, 1 = lld / Matérn-3/2
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side);
+// gen: the register kernels generate K themselves (SE)
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 // units of more than 1024 points: blocked Cholesky and forward substitution over whole launches (no-ops when the launch has none)
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);

@@ -24,8 +24,11 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <cstring>
 
 namespace gprf {
+
+int diag(const char *key, int dflt);      // GPRF_DIAG="key=value,...": see the definition
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1117,7 +1120,7 @@ __device__ __forceinline__ void mfma4_vgpr(d4 &c, const double (&a)[4], const do
 }
 
 constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the four-wave register-resident kernels take
-constexpr int POTRF_REG_LDP = 272;   // >= 16 * POTRF_REG_MAXT_C, = 16 mod 32
+
 // the eight-wave instantiation (one workgroup per CU) takes units of up to 20 tiles per edge (320 points: the seismic
 // configuration's block pairs): 8 x 20 accumulator slots hold 160 of a 20-tile unit's 190 strictly-upper tiles, the FIRST
 // 30 in row-major order (row 0 and part of row 1: they retire first and are updated at most once) wait in LDS
@@ -1146,29 +1149,25 @@ constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13
 // GEN: the kernel matrix is not read from the K pool but GENERATED here from the unit's coordinates (SE kernel):
 // k_fill does not run at all, K never exists in HBM, and the prologue's burst of tile loads (every resident unit
 // at once) becomes arithmetic spread over the launch; k_mgrad<.,.,false> re-evaluates the values it needs.
-// WPS (waves per SIMD the register budget is cut for): 1 = 512 registers per wave (32 tile slots: units up to 16
-// tiles per edge, one workgroup per CU); 2 = 256 registers per wave (20 tile slots + 96 VGPRs: units up to 13 tiles per
-// edge, TWO workgroups per CU — a unit's factorisation is a latency chain that keeps its SIMDs a quarter busy, so
-// two of them side by side nearly double the CU's throughput).  Units outside [min_T, reg_maxT] are left alone.
-// DK (GEN only): 0 = ("euclidean","se"), coordinates of XPAD doubles per point; 1 = ("lld","matern32"), the GEO_STRIDE-double
-// half-angle records (KernFn<1,1>::value per entry, k_fill<1,1>'s definition)
-// RA ("run-ahead", two-per-CU / eight-wave instantiations): no workgroup barrier inside the step loop — see the RA block.
+// Every wave has 256 registers (20 tile slots = a[0:159] + 96 VGPRs).  RW = 4: units of up to 13 tiles per edge, TWO
+// workgroups per CU — a unit's factorisation is a latency chain that keeps its SIMDs a quarter busy, so two of them side by
+// side nearly double the CU's throughput; RW = 8: one workgroup per CU, units of up to 20 (GW: 28) tiles.  Units outside
+// [min_T, reg_maxT] are left alone.  (Rounds 1-4 also had a four-wave form with 512 registers per wave, a run-ahead step
+// loop without workgroup barriers and ("lld","matern32") generation in here: each measured slower than what is left —
+// DESIGN.md section 4 — and removed in round 5.)
 // GW (eight-wave instantiation, K from the pool): units of up to 28 tiles per edge — the (up to 218) tiles beyond the
 // accumulator slots wait in GLOBAL memory instead of LDS: in the U pool, each at its own final place (nobody else touches a
 // tile of U before its row is solved), read and written through the CU's L1 / the L2 like the generic kernel's whole trailing
 // matrix — a fraction of that kernel's traffic (the first rows only, and only until they retire).  Waves of one workgroup
 // share the CU's L1: a store is visible to the other waves behind s_waitcnt vmcnt(0) + the workgroup barrier.
-template <int RW, int SLOTS, bool GEN, int WPS, int DK = 0, bool RA = false, bool GW = false>
+template <int RW, int SLOTS, bool GEN, bool GW = false>
 __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &pl, int stamps, int reg_maxT, const KParams &kp,
                                                int which, int min_T = 0) {
     static_assert(8 * SLOTS <= 256, "atile_reserve() covers a[0:255]");
-    static_assert(!GW || (RW == 8 && !GEN && !RA), "waiting tiles in the U pool: the eight-wave kernel reading the K pool");
+    static_assert(!GW || (RW == 8 && !GEN), "waiting tiles in the U pool: the eight-wave kernel reading the K pool");
     extern __shared__ double lds[];
     __shared__ int s_fail;
     __shared__ double lred[RW];
-    // RA: the four progress words: [0] diagonal tiles factored and published, [1] rows whose first tile (j, j+1) is solved,
-    // [2] solved tiles in all (cumulative), [3] wave-steps whose trailing update is finished (cumulative)
-    __shared__ int s_flags[4];
 #ifdef GPRF_WGTRACE
     __shared__ double s_tr0;       // (WgTrace itself does not survive this kernel's register discipline)
     if (threadIdx.x == 0) s_tr0 = (double)__builtin_amdgcn_s_memrealtime();
@@ -1218,15 +1217,12 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // multiply-adds per step would otherwise pile up on one SIMD: no change, 110.6 vs 109.6 us, C4 664 vs 666: they do not)
     // fixed panel pitch (an odd multiple of 16 doubles: the k-major MFMA operand reads are conflict free):
     // every LDS row offset below is an instruction immediate
-    // WPS == 2 (two workgroups per CU share the 160 KB): ONE panel buffer of pitch 240 (units of up to 13 tiles); the
-    // solved panel then goes to global memory inside its own step (copy_now below), never from the other buffer
-    constexpr bool WHOLE_CU = WPS == 1 || RW == 8;     // one workgroup per CU: the wide pitch (units of up to 16 / 20 tiles)
+    // ONE panel buffer: pitch 240 for the two-per-CU form (two workgroups share the CU's 160 KB; units of up to 13 tiles), the
+    // wide pitches for the eight-wave one; the solved panel goes to global memory from inside the row solve
     constexpr int MT = RW == 8 ? (GW ? POTRF_REG8W_MAXT : POTRF_REG8_MAXT) : POTRF_REG_MAXT_C;
-    constexpr int ldp = RW == 8 ? (GW ? POTRF_REG8W_LDP : POTRF_REG8_LDP) : (WHOLE_CU ? POTRF_REG_LDP : POTRF_REG2_LDP);
-    constexpr int NPB = WPS == 1 ? 2 : 1;
-    double *P0 = lds;                     // [NPB][16][ldp] row panel j of U in buffer j & (NPB - 1): a pure-factor wave 0
-    double *Ud = P0 + NPB * 16 * ldp;     //   writes panel j-1 back to global while panel j is being solved
-                                          // [16][16]  U_jj
+    constexpr int ldp = RW == 8 ? (GW ? POTRF_REG8W_LDP : POTRF_REG8_LDP) : POTRF_REG2_LDP;
+    double *P0 = lds;                     // [16][ldp] row panel j of U
+    double *Ud = P0 + 16 * ldp;           // [16][16]  U_jj
     double *rdt = Ud + 256;               // [16]      1 / diag(U_jj)
     double *Gd = rdt + 16;                // [16][16]  rows of G = D^-1 U_jj (unit triangular: the substitution's operand)
     double *dvals = Gd + 256;             // [16 T]    diagonal of U
@@ -1235,7 +1231,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     const double *Kp = pl.K + ur.mat_off;   // read once (upper triangle); U goes to its own pool, K stays for k_mgrad
     double *V = pl.V + (size_t)ur.row_off * 16;
     if (threadIdx.x == 0) s_fail = 0;
-    if (RA && threadIdx.x < 4) s_flags[threadIdx.x] = 0;
     unsigned glane = (unsigned)(lg * mp + lr);
     int dlane = lg * 16 + lr;             // lane's element of a row-major 16x16 tile, rows lg + 4q at + 64 q
 
@@ -1251,11 +1246,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // and CU-time is what the stage is short of: 140 us against 123 with the two instantiations)
     static_assert(RW == 4 || RW == 8, "RW - 1 workers + the factor wave");
     constexpr int NW = RW - 1;
-    // RA (run-ahead, round 4): wave 0's ov tiles are the FIRST ov tiles in row-major order (rows 0 and 1 of a 13-tile unit),
-    // all of them, instead of every fourth tile of the first 4 ov: what wave 0 carries besides the factor IS the step's
-    // critical chain once nobody waits at barriers (measured: with the four-way deal the run-ahead form gained nothing —
-    // a 13-tile unit's wave 0 still did a quarter of every substitution and trailing update through row 9, 12.7 k cycles
-    // per step); front-loaded, it is a heavy worker for two steps and a pure factor wave for the other ten.
     // n_lds: tiles beyond ALL RW * SLOTS accumulator slots (the eight-wave kernel, T = 19, 20): the first n_lds tiles in
     // row-major order stay in LDS (Ot) — solved from there when their row comes up, updated there until then; the others
     // (real index n_lds + idx) are dealt as before
@@ -1264,7 +1254,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // 15.6 k waiting for it; with its 20 tiles front-loaded (the rows right behind the waiting tiles) it is a pure factor wave
     // from step 3 on: the seismic shape's Cholesky stage 146 -> 134 us, at paper scale 1464 -> 1413.  (Units of up to 17 tiles have
     // no such tiles: nothing changes for them.  The four-wave two-per-CU kernel front-loaded: C3 109.2 -> 110, C4 662 -> 670: no.)
-    constexpr bool FRONT = RA || RW == 8;
+    constexpr bool FRONT = RW == 8;
     const int total_all = T * (T - 1) / 2;
     const int n_lds = (RW == 8 && total_all > RW * SLOTS) ? total_all - RW * SLOTS : 0;      // (RW == 4: a constant 0)
     const int total = total_all - n_lds;
@@ -1312,29 +1302,13 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // GEN: K(row, col) of this unit, exactly k_fill's definition (identity in the padding, noise + jitter on the
     // diagonal); the unit's coordinates wait in LDS
     double *xs = Dt + 256 * (T < reg_maxT ? T : reg_maxT);      // [mp][XS], GEN only (the launcher sizes the LDS)
-    constexpr int XS = DK == 1 ? GEO_STRIDE : XPAD;
+    constexpr int XS = XPAD;
     double *Ot = xs + (GEN ? 16 * (T < reg_maxT ? T : reg_maxT) * XS : 0);      // [n_lds][16][16] the tiles that wait in LDS
     const double diag_add = kp.nv + ut.jitter[u];
     // NT tiles (pk = 32 * tile row + tile column) side by side, branch-free: this wave is alone on its SIMD, so the
     // only thing that hides the latency of one exp()'s dependent chain is the other 4 NT - 1 evaluations
     auto kgen = [&](auto ntc, const int *pk, double (*out)[4], double sign) {
         constexpr int NT = decltype(ntc)::value;
-        if constexpr (DK == 1) {
-            // great-circle / Matérn-3/2: entry by entry (haversine, asin, two square roots, exp: nothing to vectorise by hand)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int col = 16 * (pk[t] & 31) + lr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int row = 16 * (pk[t] >> 5) + 4 * q + lg;
-                    double v = KernFn<1, 1>::value(kp, xs + row * XS, xs + col * XS);
-                    v = (row == col) ? __dadd_rn(v, diag_add) : v;
-                    if (!(row < m && col < m)) v = (row == col) ? 1.0 : 0.0;
-                    out[t][q] = sign * v;
-                }
-            }
-            return;
-        }
         // (round 4: in the two-per-CU instantiation two workgroups' generating waves share every SIMD and the prologue is bound
         // by instruction issue — a fifth to a quarter of a unit's time: the third coordinate's three instructions go when
         // dx <= 2 (adding (0 - 0)^2 changes no bit), and a tile whose 16 columns all lie inside the unit and off the diagonal —
@@ -1432,12 +1406,11 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     // anyway — one tile at a time here) and the tile owners form U_jk = V_jj^T C_jk with four MFMAs per tile: the accumulator
     // registers ARE the B operand (register pair q = rows 4q + lg), the product lands in D layout and goes straight to the
     // LDS panel and to global U.  No dump, no reload, no DPP on the tile owners, no copy pass.
-    double *Vd0 = Gd, *Vd1 = Ud;          // V_jj in LDS; the run-ahead form rotates two copies (Vd1 is the barrier form's U_jj staging)
-    (void)Vd1; (void)rdt;
+    double *Vd0 = Gd;                     // V_jj in LDS (Ud: U_jj staged for its way to global)
+    (void)rdt;
     // wave 0, lanes = columns of U_jj (s[k] = row k of U, rdk = 1 / U_kk of this lane's column): row lr of V_jj -> Vb (LDS,
     // row-major) and the V pool
-    // (lro: the lane's column index again, for the store addresses only — the run-ahead loop passes a copy made opaque inside
-    // the step: per-lane 64-bit pointers that are loop invariant get parked in a0..a3 at the 96-register cap)
+    // (lro: the lane's column index again, for the store addresses only)
     auto tile_inverse = [&](double (&s)[16], double rdk, int jt, double *Vb, int lro) {
         double v[16];
 #pragma unroll
@@ -1480,31 +1453,9 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         }
         tile_inverse(s, rdk, jt, Vd0, lr);
     };
-    // RA: the same, V_jj in the copy of the tile's parity, then the progress word; U_jj goes to global behind it, off the
-    // chain.  (A failed pivot poisons everything behind it with NaN; the loop runs to its end all the same — nobody may be
-    // left waiting for a word — and the first failure is what is reported.)
-    auto factor_publish_ra = [&](int jt, int lro) {
-        __builtin_amdgcn_wave_barrier();
-        double s[16], dk, rdk;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = Dt[jt * 256 + r * 16 + lr];
-        int bad = diag_factor16_ldl<NoEarly, false>(s, lr, &dk, &rdk, nullptr);
-        if (lane < 16) {
-            dvals[16 * jt + lr] = dk;
-            if (bad && lane == 0 && s_fail == 0) s_fail = 16 * jt + bad;
-        }
-        // (one base + an integer offset: a select between two LDS pointers goes through generic pointers)
-        tile_inverse(s, rdk, jt, Gd + ((jt & 1) ? -(256 + 16) : 0), lro);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) ((volatile int *)s_flags)[0] = jt + 1;
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) U[(size_t)(16 * jt + i) * mp + 16 * jt + lro] = s[i];
-        }
-    };
     // Dt[i] -= P_i^T P_i
     double *P = P0;                       // the current step's panel buffer
-    // (pl_ / dl_: this lane's offsets lg * ldp + lr into a panel row group and lg * 16 + lr into a tile — the run-ahead loop
+    // (pl_ / dl_: this lane's offsets lg * ldp + lr into a panel row group and lg * 16 + lr into a tile — the step loop
     // passes copies it has made opaque inside the step, so that the addresses built from them are not kept alive across
     // the whole loop: at the 96-register cap the compiler parked exactly those in a0 / a1, i.e. in tile slot 0)
     auto diag_update = [&](int i, int pl_, int dl_) {
@@ -1523,7 +1474,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         for (int q = 0; q < 4; ++q) Dt[i * 256 + 64 * q + dl_] = t[q] + sacc[q];
     };
     auto load_tiles = [&]() {
-        if constexpr (GEN && WPS == 2) {
+        if constexpr (GEN) {
             // one tile at a time, straight into its numbered accumulator: a runtime loop over this wave's slots (one
             // copy of the exp() code) and a jump on the wave-uniform slot number (the single panel buffer is too small
             // to stage batches in)
@@ -1539,56 +1490,10 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
                 });
             }
             return;
-        } else if constexpr (GEN) {
-            // tiles -> accumulators, 8 slots at a time: a RUNTIME loop evaluates the batch's tiles into this wave's
-            // quarter of the (still unused) panel buffers — one copy of the exp() code instead of one per slot, which
-            // would not fit the instruction cache — and a static walk moves them into the numbered accumulators
-            double *stage = P0 + wave * (8 * 256);
-            static_for<0, (SLOTS + 7) / 8>([&](auto bc) {
-                constexpr int B0 = 8 * decltype(bc)::value;
-#pragma unroll 1
-                for (int i = 0; i < 8; i += 2) {     // two tiles at a time (a wave's slots are filled from 0 up)
-                    int pk[2] = {(B0 + i < SLOTS) ? __builtin_amdgcn_readlane(pkv, B0 + i) : -1,
-                                 (B0 + i + 1 < SLOTS) ? __builtin_amdgcn_readlane(pkv, B0 + i + 1) : -1};
-                    if (pk[0] >= 0) {                // wave-uniform: only the slots this wave really owns
-                        double kv[2][4];
-                        if (WPS == 1 && pk[1] >= 0) {
-                            kgen(std::integral_constant<int, 2>{}, pk, kv, -1.0);   // MINUS the trailing tile
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) stage[(i + 1) * 256 + 64 * q + lane] = kv[1][q];
-                        } else {
-                            kgen(std::integral_constant<int, 1>{}, pk, kv, -1.0);
-                            if (WPS != 1 && pk[1] >= 0) {      // (the 256-register instantiation: one tile at a time)
-                                int pk1[1] = {pk[1]};
-                                double kv1[1][4];
-                                kgen(std::integral_constant<int, 1>{}, pk1, kv1, -1.0);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) stage[(i + 1) * 256 + 64 * q + lane] = kv1[0][q];
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) stage[i * 256 + 64 * q + lane] = kv[0][q];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                static_for<0, 8>([&](auto ic) {
-                    constexpr int S = B0 + decltype(ic)::value;
-                    if constexpr (S < SLOTS) {
-                        if (PK(S) >= 0) {
-                            double kv[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) kv[q] = stage[(S - B0) * 256 + 64 * q + lane];
-                            atile_set<S>(kv);
-                        }
-                    }
-                });
-                __builtin_amdgcn_wave_barrier();
-            });
-            return;
         }
         // tiles -> accumulators, PRO_BATCH slots at a time: all the batch's loads are issued before the first
         // (volatile) accumulator write, which nothing is moved across
-        constexpr int PRO_BATCH = WPS == 1 ? 10 : 4;      // (the 256-register instantiations: 96 VGPRs)
+        constexpr int PRO_BATCH = 4;      // (96 VGPRs)
         static_for<0, (SLOTS + PRO_BATCH - 1) / PRO_BATCH>([&](auto bc) {
             constexpr int B0 = decltype(bc)::value * PRO_BATCH;
             double kv[PRO_BATCH][4];
@@ -1612,10 +1517,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     };
     __syncthreads();
     // wave 0 factors the first diagonal tile while the workers fetch their tiles
-    if (wave == 0) {
-        if constexpr (RA) factor_publish_ra(0, lr);
-        else factor_publish(0);
-    }
+    if (wave == 0) factor_publish(0);
     if (mine) load_tiles();
     __syncthreads();
 
@@ -1855,82 +1757,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
             });
         }
     };
-    if constexpr (RA) {
-        // ---- the run-ahead pipeline: no workgroup barrier inside the step loop ----
-        // With barriers a step is  [all: substitution] | barrier | [wave 0: factor  ||  the others: trailing update] | barrier:
-        // the tile-owning waves idle while the next diagonal tile is factored, the factor wave idles during the substitution,
-        // and both pay the rendezvous twice.  Here every wave waits only for what IT needs, through four progress words in
-        // LDS (a wave's LDS operations are performed in order, so a word written behind the data it announces is enough):
-        //   * wave 0 needs the solved tile (j, j+1) — its owner solves it in its FIRST substitution pass and says so — to
-        //     update and factor the diagonal tile j+1; it publishes G_{j+1} (two copies of G / 1 / diag in rotation, so
-        //     that the substitution of step j may still be reading G_j) and only then scales and stores U_{j+1,j+1};
-        //   * a tile-owning wave needs G_j and the panel buffer free (every wave has finished its trailing update of step
-        //     j-1) to solve its tiles of row j, and ALL solved tiles of row j for its trailing update.
-        // The factor of tile j+1 thus runs beside the rest of step j's substitution and its trailing update instead of
-        // between two barriers.  Same arithmetic per tile in the same order as the barrier form: bit-identical factors
-        // (tests/test_gpu_variants.py; GPRF_POTRF_RA=0 restores the barrier form).  The solved panel goes to global U
-        // straight from the substitution (one store per row and lane next to the LDS store) instead of a copy pass.
-        static_assert(NPB == 1, "the run-ahead form is cut for one panel buffer");
-        volatile int *flg = s_flags;
-        // (bounded: a wave that has polled for ~0.2 s gives up and poisons the unit — reported like a failed pivot, never a
-        // hung queue; it cannot happen unless a progress word is lost)
-        auto wait_ge = [&](int idx, int target) {
-            int spins = 0;
-            while (__builtin_amdgcn_readfirstlane(flg[idx]) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 21)) {
-                    if (lane == 0) s_fail = 0x40000000 + 16 * idx;
-                    break;
-                }
-            }
-            asm volatile("" ::: "memory");
-        };
-        const int nwk = w0busy ? RW : NW;          // waves that own tiles
-        for (int j = 0; j + 1 < T; ++j) {
-            int lb = lg * ldp + lr, dl = dlane;
-            asm volatile("" : "+v"(lb));
-            asm volatile("" : "+v"(dl));
-            asm volatile("" : "+v"(pkv));
-            asm volatile("" : "+v"(shv));
-            const int s_lo = j > 0 ? __builtin_amdgcn_readlane(shv, j - 1) : 0;
-            const int s_hi = __builtin_amdgcn_readlane(shv, j);
-            if (mine) {
-                if (wave != 0) wait_ge(0, j + 1);          // G_j is published
-                wait_ge(3, nwk * j);                       // nobody reads panel j-1 any more
-                GPRF_STAMP2(0)
-                solve_rows(j, s_lo, s_hi, lb, dl, Gd + ((j & 1) ? -(256 + 16) : 0));
-                GPRF_STAMP2(1)
-                // (uniform) the first tile of row j, when this wave owns it, sits in its first slot of the row: tile (j, j+1)
-                // is in the panel, wave 0 may go on
-                if (s_lo < s_hi && __builtin_amdgcn_readlane(pkv, s_lo) == 33 * j + 1) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) flg[1] = j + 1;
-                }
-                if (s_hi > s_lo) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(&s_flags[2], s_hi - s_lo);
-                }
-                GPRF_STAMP2(2)
-            }
-            GPRF_STAMP(0)
-            if (wave == 0) {
-                wait_ge(1, j + 1);
-                GPRF_STAMP(1)
-                diag_update(j + 1, lb, dl);
-                factor_publish_ra(j + 1, dl & 15);
-            }
-            GPRF_STAMP(2)
-            if (mine) {
-                wait_ge(2, (j + 1) * T - ((j + 1) * (j + 2)) / 2);      // every tile of row j is solved
-                GPRF_STAMP2(3)
-                trailing_update(j, s_hi, lb, dl);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) atomicAdd(&s_flags[3], 1);
-                GPRF_STAMP2(4)
-            }
-            GPRF_STAMP(3)
-        }
-    } else
     for (int j = 0; j + 1 < T; ++j) {
         if (s_fail) break;
         // keep the per-slot tile coordinates and LDS addresses from being hoisted out of the step loop (they are
@@ -1943,7 +1769,6 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         asm volatile("" : "+v"(shv));
         const int s_lo = j > 0 ? __builtin_amdgcn_readlane(shv, j - 1) : 0;
         const int s_hi = __builtin_amdgcn_readlane(shv, j);
-        P = P0 + (j & (NPB - 1)) * 16 * ldp;
         if (wave == 0) {
             // U_jj (published in LDS by the last look-ahead) -> global, off the critical path
             for (int e = dl; e < 256; e += 64) U[(size_t)(16 * j + (e >> 4)) * mp + 16 * j + (e & 15)] = Ud[e];
@@ -2002,7 +1827,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
         if (threadIdx.x == 0) { pl.info[u] = s_fail; pl.logdet[u] = 0.0; }
         return;
     }
-    if (!RA && wave == 0) {
+    if (wave == 0) {
         int jt = T - 1;
         for (int e = lane; e < 256; e += 64) U[(size_t)(16 * jt + (e >> 4)) * mp + 16 * jt + (e & 15)] = Ud[e];
     }
@@ -2015,7 +1840,7 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
     }
 #endif
 #ifdef GPRF_WGTRACE
-    if ((WPS == 1 ? 4 : 5) == GPRF_WGTRACE && threadIdx.x == 0 && (int)blockIdx.x < GPRF_WGTRACE_MAX) {
+    if ((RW == 8 ? 4 : 5) == GPRF_WGTRACE && threadIdx.x == 0 && (int)blockIdx.x < GPRF_WGTRACE_MAX) {
         double *rec = pl.dbg + (size_t)(ut.n_units > 1 ? ut.n_units : 1) * 8 + (size_t)blockIdx.x * 4;
         unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         rec[0] = s_tr0;
@@ -2027,36 +1852,27 @@ __device__ __forceinline__ void potrf_reg_body(const UnitTab &ut, const Pools &p
 #endif
 }
 
-// the two kernels around the body (an attribute cannot depend on a template parameter): one workgroup per CU with 512
-// registers per wave, and two per CU with 256 (20 tile slots = a[0:159] + at most 96 VGPRs)
-template <int RW, int SLOTS, bool GEN>
-__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<RW, SLOTS, GEN, 1>(ut, pl, stamps, reg_maxT, kp, which);
-}
-// eight waves of 256 registers, ONE workgroup per CU (seven workers x 20 slots: every unit of up to 16 tiles): a unit
-// finishes 20 % sooner than with four waves of 512 registers (T = 15: 89 vs 104-113 us) — as the only kernel it loses (a
-// whole CU per unit: 140 vs 123 us), as the kernel of the LARGEST units, which are what the stage waits for, it is in
-// ("lld","matern32") units of up to 16 tiles per edge, K generated (round 3): the seismic configuration's unary blocks
-template <int RW, int SLOTS>
-__global__ __launch_bounds__(RW * 64, 1) void k_potrf_reg_lld(UnitTab ut, Pools pl, int stamps, int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<RW, SLOTS, true, 1, 1>(ut, pl, stamps, reg_maxT, kp, which);
-}
-template <int SLOTS, bool GEN, bool RA = false>
+// the kernels around the body (an attribute cannot depend on a template parameter).
+// Eight waves of 256 registers, ONE workgroup per CU (seven workers x 20 slots): a unit finishes 20 % sooner than it did with
+// four waves of 512 registers (T = 15: 89 vs 104-113 us) — as the only kernel it loses (a whole CU per unit: 140 vs 123 us), as
+// the kernel of the LARGEST units, which are what the stage waits for, it is in.
+template <int SLOTS, bool GEN>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8(UnitTab ut, Pools pl, int stamps,
                                                                                            int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<8, SLOTS, GEN, 2, 0, RA>(ut, pl, stamps, reg_maxT, kp, which);
+    potrf_reg_body<8, SLOTS, GEN>(ut, pl, stamps, reg_maxT, kp, which);
 }
 // ... units of 21 .. 28 tiles per edge (and, in a launch that has such units, every smaller one too), K from the pool: the
 // tiles beyond the accumulator slots wait in the U pool (GW)
 template <int SLOTS>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8w(UnitTab ut, Pools pl, int stamps,
                                                                                             int reg_maxT, KParams kp, int which, int min_T) {
-    potrf_reg_body<8, SLOTS, false, 2, 0, false, true>(ut, pl, stamps, reg_maxT, kp, which, min_T);
+    potrf_reg_body<8, SLOTS, false, true>(ut, pl, stamps, reg_maxT, kp, which, min_T);
 }
-template <int RW, int SLOTS, bool GEN, bool RA = false>
+// four waves, TWO workgroups per CU: units of up to 13 tiles per edge, K generated
+template <int RW, int SLOTS, bool GEN>
 __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg2(UnitTab ut, Pools pl, int stamps,
                                                                                                 int reg_maxT, KParams kp, int which) {
-    potrf_reg_body<RW, SLOTS, GEN, 2, 0, RA>(ut, pl, stamps, reg_maxT, kp, which);
+    potrf_reg_body<RW, SLOTS, GEN>(ut, pl, stamps, reg_maxT, kp, which);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3560,14 +3376,22 @@ static int device_cus() {
 }
 
 static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
-// group size of the part-major walk (part_major_map): GPRF_PM_GROUP, 0 = launch-wide
-static int pm_group() {
-    static const int g = [] { const char *e = getenv("GPRF_PM_GROUP"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) & ~7 : 0; }();
-    return g;
-}
-static int pm_grid(int n_ids, int nparts) {
-    const int G = pm_group();
-    return G > 0 ? ((n_ids + G - 1) / G) * G * nparts : xcd_grid(n_ids, nparts);
+// ONE diagnostic switch for everything that selects a launch structure: GPRF_DIAG="key=value,key=value".  The product path
+// sets none of them; tests/test_gpu_variants.py compares the forms they select bit for bit, scripts/ time them.
+//   fused_build=0   table build + coordinate scatter as three launches      gx_fold=0     k_gx_finalize as a launch of its own
+//   one_queue=1     both Cholesky instantiations on the main queue          side_events=1 fork / join of the two queues by events
+//   part_major=0/1  solve / gradient grids unit by unit / part by part      potrf_reg=0   every unit through the generic Cholesky
+//   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-28 tiles on the generic kernel
+//   potrf_stamps=1..3  which wave's cycle stamps a -DGPRF_PROFILE build records
+// Read at every call (a handful of string searches per evaluation): a test may change it between two contexts of one process.
+int diag(const char *key, int dflt) {
+    const char *e = getenv("GPRF_DIAG");
+    if (!e || !e[0]) return dflt;
+    const size_t kl = strlen(key);
+    for (const char *q = e; (q = strstr(q, key)) != nullptr; q += kl) {
+        if ((q == e || q[-1] == ',') && q[kl] == '=') return atoi(q + kl + 1);
+    }
+    return dflt;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4150,8 +3974,7 @@ __global__ __launch_bounds__(256) void k_build_scatter(BuildTab bt, const double
 
 // whether the single-launch form applies to this partition
 bool build_scatter_fits(const BuildTab &bt) {
-    static const bool off = [] { const char *e = getenv("GPRF_FUSED_BUILD"); return e && e[0] == '0'; }();
-    return !off && bt.n > 0 && bt.n_blocks > 0 && bt.n_blocks <= FB_MAX_BLOCKS && bt.n_local <= FB_MAX_UNITS &&
+    return diag("fused_build", 1) != 0 && bt.n > 0 && bt.n_blocks > 0 && bt.n_blocks <= FB_MAX_BLOCKS && bt.n_local <= FB_MAX_UNITS &&
            bt.n <= FB_MAX_POINTS && bt.n_ent <= FB_MAX_ENT;
 }
 void launch_build_scatter(const BuildTab &bt, const double *X, int dx, int dist_id, int force, int epoch, hipStream_t s) {
@@ -4178,45 +4001,35 @@ void launch_fill(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     int nt = (16 * ut.max_T + 63) / 64;
     dim3 grid(nt * (nt + 1) / 2, ut.n_ids);
     // Round 4, measured on C3 forced through the pool (stage us; 117 MB algorithmic, 84 MB written): the entry-by-entry form
-    // 35.9; one workgroup per 64-row strip walking its blocks (a third of the workgroups, one round of them) 53.2; eight
-    // interleaved exp chains per thread instead of four 38.0; non-temporal stores 36.0; k_fill_se, half the vector-ALU
-    // instructions per value, 26.2 = 4.5 TB/s.  GPRF_FILL_VARIANT=0: the entry-by-entry form for the SE kernel too (A/B).
-    static const bool ref_form = [] { const char *e = getenv("GPRF_FILL_VARIANT"); return e && e[0] == '0'; }();
-    if (dist_id == 0 && kern_id == 0) {
-        if (ref_form) hipLaunchKernelGGL((k_fill<0, 0>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-        else hipLaunchKernelGGL(k_fill_se, grid, dim3(256), 0, s, ut, p, kp, skip_T);
-    } else {
-        hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
-    }
+    // (k_fill<0,0>, gone since round 5) 35.9; one workgroup per 64-row strip walking its blocks (a third of the workgroups, one
+    // round of them) 53.2; eight interleaved exp chains per thread instead of four 38.0; non-temporal stores 36.0; k_fill_se,
+    // half the vector-ALU instructions per value, 26.2 = 4.5 TB/s algorithmic
+    if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL(k_fill_se, grid, dim3(256), 0, s, ut, p, kp, skip_T);
+    else hipLaunchKernelGGL((k_fill<1, 1>), grid, dim3(256), 0, s, ut, p, kp, skip_T);
 }
 
-constexpr int POTRF_REG_WAVES = 4;    // k_potrf_reg: one wave per SIMD, 256 VGPRs + 256 AGPRs each
-constexpr int POTRF_REG_SLOTS = 32;   // 3 workers x 32 slots >= 14*13/2 strictly-upper tiles (all 256 AGPRs)
-constexpr int POTRF_REG_MAXT = POTRF_REG_MAXT_C;    // -> units of up to 256 points
+constexpr int POTRF_REG_WAVES = 4;      // the two-per-CU instantiation: one wave per SIMD and workgroup
+constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
+constexpr int POTRF_SMALL_MAXT = 13;
+// (the eight-wave instantiation — the large-unit kernel of the two-queue SE path, and the non-generating register kernel —
+// takes units of up to POTRF_REG8_MAXT tiles per edge: 140 .. 160 tiles in accumulators, up to 30 more waiting in LDS)
 
-// Where a unit's kernel matrix comes from is decided PER UNIT: units of at most potrf_gen_maxT() tiles per edge (256
+// Where a unit's kernel matrix comes from is decided PER UNIT: units of at most potrf_gen_maxT() tiles per edge (320
 // points) have it generated inside the register-resident Cholesky (SE kernel) — k_fill skips them and K never exists in
-// HBM for them — larger ones are filled into the K pool and factored by the generic kernel.  (Round 2 decided per
-// launch: one pair growing past 256 points during an optimisation sent all 442 units of the north-star configuration
-// through the K pool: +36 us fill, +12 us in the Cholesky.)  k_mgrad re-evaluates the values it needs in both cases.
-static bool potrf_use_reg(const UnitTab &ut) {
-    const char *rg = getenv("GPRF_POTRF_REG");
-    // (round 1's rule "at most 4 units per CU, else the generic two-per-CU kernel" predates the two-per-CU register
-    // instantiation: with it the register path also wins at C4's 4033 units — no K pool to fill and read back:
-    // fill + Cholesky 1081 -> 716 us, the evaluation 3.05 -> 2.80 ms)
-    (void)ut;
-    return (rg && (rg[0] == '0' || rg[0] == '1')) ? rg[0] == '1' : true;
-}
-static bool potrf_gw();
+// HBM for them — larger ones are filled into the K pool.  (Round 2 decided per launch: one pair growing past the limit
+// during an optimisation sent all 442 units of the north-star configuration through the K pool: +36 us fill, +12 us in the
+// Cholesky.)  k_mgrad re-evaluates the values it needs in both cases.
+// diag potrf_reg=0: every unit through the generic kernel (tests: the register kernels against it, bit for bit)
+static bool potrf_use_reg() { return diag("potrf_reg", 1) != 0; }
+// units of 21 .. 28 tiles per edge on the eight-wave kernel with its waiting tiles in the U pool (diag potrf_gw=0: the generic
+// kernel)
+static bool potrf_gw() { return diag("potrf_gw", 1) != 0; }
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
-    const char *e = getenv("GPRF_FUSED_FILL");      // =0: always fill the K pool (diagnostics, A/B timing)
-    const bool off = e && e[0] == '0';
-    // ("lld","matern32") generation is built and tested but OFF by default: on the seismic configuration's shape the unary
-    // blocks' kernel then spends 90 us generating (haversine + asin + two square roots + exp per entry, four lone waves)
-    // in front of the generic kernel instead of 52 us reading — fill 77 -> 64 us, Cholesky stage 250 -> 289 us.
-    // GPRF_LLD_GEN=1 turns it on.
-    static const bool lld_gen = [] { const char *g = getenv("GPRF_LLD_GEN"); return g && g[0] == '1'; }();
-    const bool se = dist_id == 0 && kern_id == 0, lld = dist_id == 1 && kern_id == 1 && lld_gen;
+    // (diag fused_fill=0: always fill the K pool.  ("lld","matern32") generation inside the register kernel was built in
+    // round 3 and measured a loss — the unary blocks' kernel spent 90 us generating, haversine + asin + two square roots + exp
+    // per entry on four lone waves, in front of the generic kernel instead of 52 us reading: Cholesky stage 250 -> 289 us —
+    // and is gone since round 5)
+    const bool se = dist_id == 0 && kern_id == 0;
     // a launch with units of more than 20 tiles per edge goes through the K pool as a whole: ONE eight-wave kernel then takes
     // every unit of up to 28 tiles (waiting tiles in the U pool) — behind the generating kernels it would run by itself, a
     // unit's whole chain later (measured, 49 blocks of ~184 points + 156 pairs of 20-27 tiles: fill + Cholesky 32 + 281 us
@@ -4225,23 +4038,11 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     // growing past 320 points) leave the others generated, as round 2 decided per unit: they are filled, and take the
     // eight-wave kernel (up to 28 tiles) or the generic one behind the generating kernels.
     if (ut.max_T > 20 && potrf_gw() && ut.n_wide >= 16 && 8 * ut.n_wide >= ut.n_ids) return false;
-    return !off && (se || lld) && ut.n_ids > 0 && potrf_use_reg(ut);
+    return diag("fused_fill", 1) != 0 && se && ut.n_ids > 0 && potrf_use_reg();
 }
-constexpr int POTRF_SMALL_SLOTS = 20;   // 4 waves x 20 slots >= 13*12/2 strictly-upper tiles: units up to 208 points
-// (the eight-wave instantiation — the large-unit kernel of the two-queue SE path, and the non-generating register kernel —
-// takes units of up to POTRF_REG8_MAXT tiles per edge: 140 .. 160 tiles in accumulators, up to 30 more waiting in LDS)
-static bool potrf_big8() {
-    static const bool big8 = [] { const char *e = getenv("GPRF_POTRF_BIG8"); return !(e && e[0] == '0'); }();
-    return big8;
-}
-bool potrf_dual_enabled();
-int potrf_gen_maxT(int dist_id) { return dist_id == 0 && potrf_dual_enabled() && potrf_big8() ? POTRF_REG8_MAXT : POTRF_REG_MAXT_C; }
-// units of 21 .. 28 tiles per edge on the eight-wave kernel with its waiting tiles in the U pool (GPRF_POTRF_GW=0: the generic
-// kernel, diagnostics)
-static bool potrf_gw() {
-    static const bool on = [] { const char *e = getenv("GPRF_POTRF_GW"); return !(e && e[0] == '0'); }();
-    return on && potrf_big8();
-}
+int potrf_gen_maxT(int) { return POTRF_REG8_MAXT; }
+int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
+
 static void launch_reg8w(dim3 grid, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, const KParams &kp, int min_T) {
     const int capT = ut.max_T < POTRF_REG8W_MAXT ? ut.max_T : POTRF_REG8W_MAXT;
     const size_t lds = (size_t)(16 * POTRF_REG8W_LDP + 256 + 16 + 256 + 16 * POTRF_REG8W_MAXT + 256 * capT) * sizeof(double);
@@ -4254,58 +4055,21 @@ static size_t potrf_reg8_lds(int capT, int xs_stride) {
     const int total = capT * (capT - 1) / 2, n_lds = total > 8 * 20 ? total - 8 * 20 : 0;
     return (size_t)(16 * POTRF_REG8_LDP + 256 + 16 + 256 + 16 * POTRF_REG8_MAXT + 256 * capT + 16 * capT * xs_stride + 256 * n_lds);
 }
-
-constexpr int POTRF_SMALL_MAXT = 13;
-bool potrf_dual_enabled() {             // GPRF_POTRF_DUAL=0: one instantiation only (diagnostics)
-    static const bool on = [] { const char *e = getenv("GPRF_POTRF_DUAL"); return !(e && e[0] == '0'); }();
-    return on;
-}
-int potrf_small_maxT() { return POTRF_SMALL_MAXT; }
-
-// How the two Cholesky queues wait for each other (launch_potrf): 4 = the large-unit kernel's first workgroup writes the word
-// the side queue waits for + join by stream memory operation (the product path); 0 = events both ways.
-// Any environment that may serialise dispatches across queues — a profiler or debug agent loaded into the runtime,
-// serialised / blocking launches — gets the fork and the join as EVENTS: dependencies the runtime itself resolves (slower:
-// stage 131 vs 110 us), where a stream wait on a word that a kernel of the other queue writes would never return.
-// (finish_eval bounds its wait all the same.)  GPRF_SIDE_MODE = 0..4 forces one (diagnostics).  Reported by
-// gprf_runtime_config(), so that a trace taken under a tool is labelled with the launch structure it shows.
-// the two-per-CU and the eight-wave instantiation, in the barrier form (default) or the run-ahead form (GPRF_POTRF_RA=1).
-// Measured (round 4, C3 stage / N = 8 shard / C4, us): with the substitution panel both forms 118 / 101-103 / 717-727; with
-// the matrix-pipe panel barriers 109 / 90 / 654, run-ahead 116 / 94 / 684 — once the tile owners' step is short, polling
-// four progress words costs more than two barriers, and the waits it removes were never the bound (these kernels are
-// bound by instruction issue: two workgroups, or two waves of one, share every SIMD).  Kept: bit-identical, tested.
-bool potrf_run_ahead() {
-    static const bool on = [] { const char *e = getenv("GPRF_POTRF_RA"); return e && e[0] == '1'; }();
-    return on;
-}
 static void launch_reg2(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, int maxT,
                         const KParams &kp, int which) {
-    if (potrf_run_ahead()) {
-        if (lds_needs_optin(6, lds))
-            (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true, true>), grid, dim3(POTRF_REG_WAVES * 64), lds, s,
-                           ut, p, stamps, maxT, kp, which);
-    } else {
-        if (lds_needs_optin(3, lds))
-            (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), grid, dim3(POTRF_REG_WAVES * 64), lds, s, ut,
-                           p, stamps, maxT, kp, which);
-    }
+    if (lds_needs_optin(3, lds))
+        (void)hipFuncSetAttribute((const void *)k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_potrf_reg2<POTRF_REG_WAVES, POTRF_SMALL_SLOTS, true>), grid, dim3(POTRF_REG_WAVES * 64), lds, s, ut,
+                       p, stamps, maxT, kp, which);
 }
 static void launch_reg8(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut, const Pools &p, int stamps, int maxT,
-                        const KParams &kp, int which, bool gen = true) {
+                        const KParams &kp, int which, bool gen) {
     if (!gen) {
         if (lds_needs_optin(8, lds))
             (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, false>), grid, dim3(512), lds, s, ut, p, stamps, maxT, kp, which);
-    } else if (potrf_run_ahead()) {
-        if (lds_needs_optin(7, lds))
-            (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_potrf_reg8<POTRF_SMALL_SLOTS, true, true>), grid, dim3(512), lds, s, ut, p, stamps, maxT, kp, which);
     } else {
         if (lds_needs_optin(4, lds))
             (void)hipFuncSetAttribute((const void *)k_potrf_reg8<POTRF_SMALL_SLOTS, true>,
@@ -4314,6 +4078,11 @@ static void launch_reg8(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut,
     }
 }
 
+// Any environment that may serialise dispatches across queues — a profiler or debug agent loaded into the runtime,
+// serialised / blocking launches — gets the fork and the join of the two Cholesky queues as EVENTS: dependencies the runtime
+// itself resolves (slower: stage 131 vs 110 us), where a stream wait on a word that a kernel of the other queue writes would
+// never return.  (finish_eval bounds its wait all the same.)  Reported by gprf_runtime_config(), so that a trace taken under
+// a tool is labelled with the launch structure it shows.
 bool potrf_tool_env() {
     static const bool tool_env = [] {
         for (const char *v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "AMD_SERIALIZE_KERNEL",
@@ -4325,202 +4094,132 @@ bool potrf_tool_env() {
     }();
     return tool_env;
 }
-int potrf_side_mode() {
-    static const int side_mode = [] { const char *e = getenv("GPRF_SIDE_MODE"); return e ? atoi(e) : (potrf_tool_env() ? 0 : 4); }();
-    return side_mode;
+// 4 = the large-unit kernel's first workgroup writes the word the side queue waits for + join by stream memory operation (the
+// product path); 0 = events both ways (under a tool; diag side_events=1).  (Round 2 measured the mixtures — memory operations
+// both ways 177 us, fork by memory operation + join by event 181, fork by event + join by memory operation 121 — gone.)
+int potrf_side_mode() { return (potrf_tool_env() || diag("side_events", 0)) ? 0 : 4; }
+// rocprofv3 collecting hardware counters serialises the dispatches of ALL queues, and the stream-memory-operation wait that
+// joins the two queues in front of the solve would never see its value written (observed: the run hangs): both
+// instantiations then go one after the other on the main queue (diag one_queue=1: the same, for standalone durations)
+static bool potrf_one_queue() {
+    static const bool counters = [] {
+        const char *c = getenv("ROCPROF_COUNTER_COLLECTION");
+        return c && c[0] && c[0] != '0' && c[0] != 'F' && c[0] != 'f';
+    }();
+    return counters || diag("one_queue", 0) != 0;
 }
 
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, int dk, hipStream_t s, const SideQueue &side) {
+void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side) {
     if (ut.n_ids == 0) return;
     hipStream_t s2 = side.s2;
-    const char *st = getenv("GPRF_POTRF_STAMPS");   // diagnostic: in-kernel cycle stamps into Pools::dbg
-    int stamps = (st && st[0] >= '1' && st[0] <= '3') ? st[0] - '0' : 0;
-    // The register-resident kernel holds a whole CU per unit (one wave per SIMD): it wins on latency while the
-    // launch is a few rounds of workgroups deep (C3: 442 units, 124 vs 145 us), the 2-workgroups-per-CU generic
-    // kernel wins on throughput beyond that (C4 on one GPU: 4033 units, 857 vs 914 us).
-    // GPRF_POTRF_REG=0 / 1 forces one or the other (diagnostics).
-    bool use_reg = potrf_use_reg(ut);
-    int reg_maxT = use_reg ? POTRF_REG_MAXT : 0;
-    // (the eight-wave instantiation takes units of up to 20 tiles: the non-generating path as a whole, the SE path's large-unit
-    // list)
-    const bool dual = potrf_dual_enabled();
-    const bool wide = use_reg && potrf_big8() && (gen ? (dk == 0 && dual) : true);
-    if (wide) reg_maxT = POTRF_REG8_MAXT;
+    const int stamps = diag("potrf_stamps", 0);      // diagnostic builds (-DGPRF_PROFILE): in-kernel cycle stamps into Pools::dbg
+    // every unit of up to 20 tiles per edge on the register-resident kernels (28 with its waiting tiles in the U pool), the
+    // generic kernel above that
+    int reg_maxT = potrf_use_reg() ? POTRF_REG8_MAXT : 0;
     // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
     auto launch_generic = [&]() {
         if (ut.max_T <= reg_maxT) return;
         // the few units of 21 .. 28 tiles per edge of a generating launch: the eight-wave kernel with its waiting tiles in the
         // U pool, from the K pool (they were filled), behind the generating kernels; the generic kernel above that
-        if (gen && wide && dk == 0 && potrf_gw() && reg_maxT == POTRF_REG8_MAXT) {
+        if (gen && potrf_gw() && reg_maxT == POTRF_REG8_MAXT) {
             launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, POTRF_REG8_MAXT + 1);
             reg_maxT = POTRF_REG8W_MAXT;
             if (ut.max_T <= reg_maxT) return;
         }
-
         const int capG = ut.max_T < SMALL_MAX_T ? ut.max_T : SMALL_MAX_T;      // (larger units: launch_big_potrf)
         size_t ldsg = (size_t)(16 * (16 * capG + 16) + 256 + 16 + 16 * 17 + 256 + 16 * capG) * sizeof(double);
         if (lds_needs_optin(1, ldsg))
             (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
         hipLaunchKernelGGL(k_potrf, dim3(ut.n_ids), dim3(POTRF_WAVES * 64), ldsg, s, ut, p, stamps, reg_maxT);
     };
-    if (reg_maxT) {
-        int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
-        const int capT4 = capT < POTRF_REG_MAXT ? capT : POTRF_REG_MAXT;       // the four-wave instantiations' share
-        size_t lds = (size_t)(2 * 16 * POTRF_REG_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT4) * sizeof(double);
-        if (gen && dk == 1) {
-            // ("lld","matern32"): one instantiation over every unit of up to 16 tiles (no size classes: the class lists are
-            // built for the SE path only); larger units were filled and go to the generic kernel
-            lds += (size_t)(16 * capT * GEO_STRIDE) * sizeof(double);
-            if (lds_needs_optin(5, lds))
-                (void)hipFuncSetAttribute((const void *)k_potrf_reg_lld<POTRF_REG_WAVES, POTRF_REG_SLOTS>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_potrf_reg_lld<POTRF_REG_WAVES, POTRF_REG_SLOTS>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
-                               ut, p, stamps, reg_maxT, kp, 0);
-            launch_generic();
-            return;
+    if (!reg_maxT) {
+        launch_generic();
+        return;
+    }
+    const int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
+    if (!gen) {
+        // the K pool's units of up to 20 tiles, eight waves a unit, one launch over the launch order (longest units first)
+        if (ut.max_T > POTRF_REG8_MAXT && potrf_gw()) {
+            // (a launch with units above 20 tiles: ONE instantiation for everything of up to 28 — two launches on one
+            // stream would run one after the other)
+            launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, 0);
+            reg_maxT = POTRF_REG8W_MAXT;
+        } else
+            launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
+        launch_generic();
+        return;
+    }
+    if (ut.max_T <= POTRF_SMALL_MAXT) {      // every unit has at most 13 tiles: the two-per-CU kernel alone
+        size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
+        launch_reg2(dim3(ut.n_ids), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
+        return;
+    }
+    // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the larger ones one to a
+    // CU; each over its own device-built list (an early-exit workgroup of the eight-wave kernel still needs an EMPTY CU to
+    // be scheduled and would stall behind the two-per-CU kernel's residents: the grids follow the list lengths of the last
+    // synchronised partition with a little slack)
+    if (potrf_one_queue() || !s2) s2 = s;
+    const int capS = POTRF_SMALL_MAXT;
+    const size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
+    // measured on the north-star configuration (stage time, us): events both ways 131; no fork command — the large-unit
+    // kernel's first workgroup writes the word the side queue waits for — + join by memory operation: 110 (an event fork
+    // costs 12 us, all of it in front of the small-unit kernel, which finishes last)
+    const bool values = side.words && potrf_side_mode() == 4;
+    const bool fork_kernel = values && ut.grid_big > 0 && s2 != s;      // (only when that kernel is really launched)
+    UnitTab utb = ut;
+    if (fork_kernel) { utb.fork_flag = side.words + 2; utb.fork_seq = side.seq; }
+    if (s2 != s && !fork_kernel) {      // fork: the side queue starts when everything enqueued on s so far is done
+        (void)hipEventRecord(side.ev_fork, s);
+        (void)hipStreamWaitEvent(s2, side.ev_fork, 0);
+    }
+    // (the large-unit kernel must go FIRST and on the main queue: launched behind the two-per-CU kernel it waits for whole
+    // CUs to drain — measured: stage 178-264 us instead of 121)
+    if (ut.grid_big > 0)
+        launch_reg8(dim3(ut.grid_big), potrf_reg8_lds(capT, XPAD) * sizeof(double), s, utb, p, stamps, reg_maxT, kp, 1, true);
+    if (fork_kernel) {
+        // (should that launch ever be refused, nothing would write the word the side queue waits for)
+        if (hipPeekAtLastError() != hipSuccess) (void)hipStreamWriteValue32(s, side.words + 2, side.seq, 0);
+        // The wait goes in BEHIND the kernel that satisfies it, in host order: HIP streams share a few hardware queues, which
+        // drain in submission order — a wait submitted ahead of its writer blocks the writer whenever the two streams land on
+        // the same hardware queue (observed: ten contexts enqueued back to back hang).  Every wait in this file depends on
+        // something submitted earlier.
+        (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+    }
+    if (ut.grid_small > 0) launch_reg2(dim3(ut.grid_small), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
+    if (s2 != s) {      // join
+        if (values) {
+            (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);
+            (void)hipStreamWaitValue32(s, side.words + 1, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+        } else {
+            (void)hipEventRecord(side.ev_join, s2);
+            (void)hipStreamWaitEvent(s, side.ev_join, 0);
         }
-        if (gen) {
-            lds += (size_t)(16 * capT4 * XPAD) * sizeof(double);     // the unit's coordinates
-            // GPRF_POTRF_DUAL=2 (diagnostic: standalone durations) — and whenever rocprofv3 collects hardware counters: the
-            // profiler then serialises the dispatches of ALL queues, and the stream-memory-operation wait that joins the two
-            // queues in front of the solve would never see its value written (observed: the run hangs)
-            static const bool serial = [] {
-                const char *e = getenv("GPRF_POTRF_DUAL");
-                const char *c = getenv("ROCPROF_COUNTER_COLLECTION");
-                return (e && e[0] == '2') || (c && c[0] && c[0] != '0' && c[0] != 'F' && c[0] != 'f');
-            }();
-            if (serial) s2 = s;      // the two instantiations one after the other on the main queue
-            // (any OTHER environment that may serialise dispatches across queues: events, see potrf_side_mode)
-            if (dual && !s2) s2 = s;
-            if (dual && ut.max_T > POTRF_SMALL_MAXT) {
-                // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the
-                // larger ones one to a CU; each skips the other's units
-                int capS = POTRF_SMALL_MAXT;
-                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capS + 16 * capS * XPAD) * sizeof(double);
-                if (lds_needs_optin(2, lds))
-                    (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                // measured on the north-star configuration (stage time, us): events both ways 131; memory operations
-                // both ways 177; fork by memory operation + join by event 181; fork by event + join by memory operation
-                // 121 (the write in front of the large-unit kernel holds that kernel back; the wait in front of the
-                // solve does not).  GPRF_SIDE_MODE = 0 / 1 / 2 / 3 selects them in that order (diagnostics).
-                // 4 (default): no fork command — the large-unit kernel's first workgroup writes the word the side queue
-                // waits for — + join by memory operation: stage 110 (the event fork costs 12 us, all of it in front of the
-                // small-unit kernel, which finishes last)
-                const int side_mode = potrf_side_mode();
-                const bool fork_values = side.words && (side_mode == 1 || side_mode == 2);
-                const bool join_values = side.words && (side_mode == 1 || side_mode == 3 || side_mode == 4);
-                // mode 4: no fork command at all — the large-unit kernel's first workgroup writes the word the side queue
-                // waits for (only when that kernel is really launched)
-                const bool fork_kernel = side.words && side_mode == 4 && ut.grid_big > 0 && s2 != s;
-                UnitTab utb = ut;
-                if (fork_kernel) { utb.fork_flag = side.words + 2; utb.fork_seq = side.seq; }
-                if (s2 != s && !fork_kernel) {      // fork: the side queue starts when everything enqueued on s so far is done
-                    if (fork_values) {
-                        (void)hipStreamWriteValue32(s, side.words, side.seq, 0);
-                        (void)hipStreamWaitValue32(s2, side.words, side.seq, hipStreamWaitValueGte, 0xffffffffu);
-                    } else {
-                        (void)hipEventRecord(side.ev_fork, s);
-                        (void)hipStreamWaitEvent(s2, side.ev_fork, 0);
-                    }
-                }
-                // (the large-unit kernel must go FIRST and on the main queue: launched behind the two-per-CU kernel it waits
-                // for whole CUs to drain — measured: stage 178-264 us instead of 121)
-                // each instantiation over its own device-built list (an early-exit workgroup of the 512-register
-                // kernel still needs an EMPTY CU to be scheduled and would stall behind the two-per-CU kernel's residents:
-                // the grids follow the list lengths of the last synchronised partition with a little slack)
-                const bool big8 = potrf_big8();
-                if (ut.grid_big > 0 && big8) {
-                    size_t lds8 = potrf_reg8_lds(capT, XPAD) * sizeof(double);
-                    launch_reg8(dim3(ut.grid_big), lds8, s, utb, p, stamps, reg_maxT, kp, 1);
-                } else if (ut.grid_big > 0)
-                    hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.grid_big),
-                                       dim3(POTRF_REG_WAVES * 64), lds, s, utb, p, stamps, reg_maxT, kp, 1);
-                if (fork_kernel) {
-                    // (should that launch ever be refused, nothing would write the word the side queue waits for)
-                    if (hipPeekAtLastError() != hipSuccess) (void)hipStreamWriteValue32(s, side.words + 2, side.seq, 0);
-                    // The wait goes in BEHIND the kernel that satisfies it, in host order: HIP streams share a few
-                    // hardware queues, which drain in submission order — a wait submitted ahead of its writer blocks the
-                    // writer whenever the two streams land on the same hardware queue (observed: ten contexts enqueued
-                    // back to back hang).  Every wait in this file depends on something submitted earlier.
-                    (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
-                }
-                if (ut.grid_small > 0) launch_reg2(dim3(ut.grid_small), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
-                if (s2 != s) {      // join
-                    if (join_values) {
-                        (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);
-                        (void)hipStreamWaitValue32(s, side.words + 1, side.seq, hipStreamWaitValueGte, 0xffffffffu);
-                    } else {
-                        (void)hipEventRecord(side.ev_join, s2);
-                        (void)hipStreamWaitEvent(s, side.ev_join, 0);
-                    }
-                }
-                launch_generic();
-                return;
-            }
-            if (ut.max_T <= POTRF_SMALL_MAXT && dual) {
-                size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
-                launch_reg2(dim3(ut.n_ids), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
-                return;      // (every unit has at most 13 tiles here)
-            }
-            // (one instantiation: GPRF_POTRF_DUAL=0 — reg_maxT is 16 then, see wide)
-            if (lds_needs_optin(2, lds))
-                (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, true>), dim3(ut.n_ids),
-                               dim3(POTRF_REG_WAVES * 64), lds, s, ut, p, stamps, reg_maxT, kp, 0);
-            launch_generic();
-            return;
-        }
-        if (wide) {
-            // the K pool's units of up to 20 tiles, eight waves a unit, one launch over the launch order (longest units first)
-            if (ut.max_T > POTRF_REG8_MAXT && potrf_gw()) {
-                // (a launch with units above 20 tiles: ONE instantiation for everything of up to 28 — two launches on one
-                // stream would run one after the other)
-                launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, 0);
-                reg_maxT = POTRF_REG8W_MAXT;
-            } else
-                launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
-            launch_generic();
-            return;
-        }
-        if (lds_needs_optin(0, lds))
-            (void)hipFuncSetAttribute((const void *)k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_potrf_reg<POTRF_REG_WAVES, POTRF_REG_SLOTS, false>), dim3(ut.n_ids), dim3(POTRF_REG_WAVES * 64), lds, s,
-                           ut, p,
-                           stamps, reg_maxT, kp, 0);
     }
     launch_generic();
 }
 
-// units of 13 .. 16 tiles: the single-buffer form at THREE workgroups per CU (35 KB of LDS, 157 VGPRs) against the
-// double-buffered 18-tile instantiation's two — round 4, measured: C3 87 -> 79 us, C4 633 -> 596 (GPRF_SOLVE16_SINGLE=0: the
-// double-buffered form; diagnostics)
-static bool solve16_single() {
-    static const bool on = [] { const char *e = getenv("GPRF_SOLVE16_SINGLE"); return !(e && e[0] == '0'); }();
-    return on;
-}
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0) return;
-    // PM: the grid walked part by part (part_major_map) — launches several rounds deep; GPRF_PART_MAJOR=0 / 1 forces
-    static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool pm = pm_env >= 0 ? pm_env == 1 : ut.n_ids <= 2 * device_cus();
+    // PM: the grid walked part by part (part_major_map) — launches at most two rounds of CUs wide; diag part_major=0 / 1 forces
+    const int pm_d = diag("part_major", -1);
+    const bool pm = pm_d >= 0 ? pm_d == 1 : ut.n_ids <= 2 * device_cus();
     // (GPRF_ONLY_POTRF: tests/test_isa_invariants.py compiles this file for the Cholesky kernels' ISA alone — the dozen
     // unrolled k_solve_panel / k_mgrad instantiations are two thirds of the compile time)
 #ifndef GPRF_ONLY_POTRF
     if (ut.max_T <= SOLVE_PANEL_MAXT) {
         const int nparts = (ut.max_T + 3) / 4 + 1;
-        dim3 grid(pm ? pm_grid(ut.n_ids, nparts) : xcd_grid(ut.n_ids, nparts));
+        dim3 grid(xcd_grid(ut.n_ids, nparts));
         UnitTab utp = ut;
-        utp.pm_group = pm_group();
+        utp.pm_group = 0;
         if (ut.max_T <= 12) {
             if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        } else if (ut.max_T <= 16 && solve16_single()) {      // (one panel buffer, three workgroups per CU)
+        } else if (ut.max_T <= 16) {
+            // units of 13 .. 16 tiles: ONE panel buffer at THREE workgroups per CU (35 KB of LDS, 157 VGPRs) against the
+            // double-buffered 18-tile instantiation's two — round 4, measured: C3 87 -> 79 us, C4 633 -> 596
             if (pm) hipLaunchKernelGGL((k_solve_panel<16, 3, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<16, 3, false, 1>), grid, dim3(256), 0, s, ut, p, kp.dy);
-        } else if (ut.max_T <= 18) {      // (an exact 16-tile instantiation is slower: 82 vs 79 us, C4 674 vs 640)
+        } else if (ut.max_T <= 18) {
             if (pm) hipLaunchKernelGGL((k_solve_panel<18, 2, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<18, 2, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
         } else if (ut.max_T <= 20) {
@@ -4553,18 +4252,14 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
     // single-unit latency matters while the launch is about one workgroup-round deep (sharded runs); beyond
     // that the wide form's operand reuse wins (C3 on one GPU: 55 vs 58 us, C4: 324 vs 429 us)
-    // GPRF_AT_WIDE=0 / 1 forces one or the other (diagnostics)
-    const char *aw = getenv("GPRF_AT_WIDE");
-    bool wide = (aw && (aw[0] == '0' || aw[0] == '1')) ? aw[0] == '1' : ut.n_ids > device_cus();
-    if (!wide)
+    const int cus = device_cus();
+    if (ut.n_ids <= cus) {
         hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
-    else
-    {
-        static const bool rev = [] { const char *e = getenv("GPRF_AT_REVERSE"); return !(e && e[0] == '0'); }();
-        const int cus = device_cus();
-        const int first_round = (rev && ut.max_T <= 16 && ut.n_ids > cus && ut.n_ids <= 2 * cus) ? cus : 0;
-        hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round);
+        return;
     }
+    // ONE round of at most two workgroups per CU: the second resident of a CU in ASCENDING size (largest with smallest)
+    const int first_round = (ut.max_T <= 16 && ut.n_ids <= 2 * cus) ? cus : 0;
+    hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round);
 }
 
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s) {
@@ -4577,22 +4272,19 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     if (ut.n_ids == 0 || ut.max_T == 0) return;
 #ifndef GPRF_ONLY_POTRF
     int TBm = (ut.max_T + 3) / 4;
-    static const int pm_env = [] { const char *e = getenv("GPRF_PART_MAJOR"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    // (only while the launch is a few rounds deep: with thousands of units the ten workgroups of a unit would run far apart
-    // and each fetch the unit's W / At from HBM again — C4: 809 vs 775 us)
-    // (round 4: deeper launches part by part too, in GROUPS of 64 launch slots — a unit's workgroups then run within one L2
-    // residency window and longest first inside the group: C4 762 -> 738 us; launch-wide groups there were the 809)
-    const bool deep = ut.n_ids > 2 * device_cus();
-    const int pm = pm_env >= 0 ? pm_env : 1;
-    const int G = pm_group() > 0 ? pm_group() : (deep ? 64 : 0);
-    dim3 grid(pm ? (G > 0 ? ((ut.n_ids + G - 1) / G) * G * (TBm * (TBm + 1) / 2) : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2))
-                 : xcd_grid(ut.n_ids, TBm * (TBm + 1) / 2));
+    // part by part (longest workgroups first): launch-wide while the launch is at most two rounds of CUs wide; deeper launches
+    // in GROUPS of 64 launch slots — a unit's workgroups then run within one L2 residency window and longest first inside the
+    // group (C4: 762 -> 738 us; launch-wide there the ten workgroups of a unit run far apart and each fetches the unit's W / At
+    // from HBM again: 809).  diag part_major=0: unit by unit.
+    const int pm = diag("part_major", 1) != 0 ? 1 : 0;
+    const int G = ut.n_ids > 2 * device_cus() ? 64 : 0;
+    const int nbp = TBm * (TBm + 1) / 2;
+    dim3 grid(pm && G > 0 ? ((ut.n_ids + G - 1) / G) * G * nbp : xcd_grid(ut.n_ids, nbp));
     UnitTab utp = ut;
     utp.pm_group = G;
     if (dist_id == 0 && kern_id == 0) {
         // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
-        int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
-        if (const char *e = getenv("GPRF_MGRAD_FAST")) { if (e[0] == '0') fast = 0; }      // diagnostics: general form
+        const int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
         if (have_K) {
             if (fast == 1) hipLaunchKernelGGL((k_mgrad<0, 0, true, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
             else if (fast == 2) hipLaunchKernelGGL((k_mgrad<0, 0, true, 2>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);

@@ -1,9 +1,10 @@
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPRF_POTRF_STAMPS", "1")
-mode2 = os.environ["GPRF_POTRF_STAMPS"] == "2"
-mode3 = os.environ["GPRF_POTRF_STAMPS"] == "3"
+STAMPS = os.environ.get("STAMPS", "1")      # which wave's stamps: 1 | 2 | 3
+os.environ["GPRF_DIAG"] = "potrf_stamps=" + STAMPS
+mode2 = STAMPS == "2"
+mode3 = STAMPS == "3"
 from gprf_amd import GPCov, Blocker, grid_centers
 from gprf_amd.gprf import GPRF
 rng = np.random.RandomState(1)

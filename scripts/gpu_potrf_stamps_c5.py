@@ -1,10 +1,11 @@
-"""Cholesky step-loop stamps on the seismic shape (GPRF_LIB = a -DGPRF_PROFILE build; GPRF_POTRF_STAMPS = 1 | 2 | 3):
-    GPRF_LIB=build_variants/libgprf_profile.so GPRF_POTRF_STAMPS=3 python scripts/gpu_potrf_stamps_c5.py [n]"""
+"""Cholesky step-loop stamps on the seismic shape (GPRF_LIB = a -DGPRF_PROFILE build; STAMPS = 1 | 2 | 3):
+    GPRF_LIB=build_variants/libgprf_profile.so STAMPS=3 python scripts/gpu_potrf_stamps_c5.py [n]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPRF_POTRF_STAMPS", "1")
-mode = os.environ["GPRF_POTRF_STAMPS"]
+STAMPS = os.environ.get("STAMPS", "1")      # which wave's stamps: 1 | 2 | 3
+os.environ["GPRF_DIAG"] = "potrf_stamps=" + STAMPS
+mode = STAMPS
 from gprf_amd import GPCov, seismic
 from gprf_amd.gprf import GPRF
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000

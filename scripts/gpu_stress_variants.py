@@ -1,6 +1,5 @@
 """Stress walk: N sequential evaluations of the north-star shape, every one re-partitioning on the device; prints a digest of
-everything returned.  Run it twice, and once with the diagnostic switches off (GPRF_FUSED_BUILD=0 GPRF_GX_FOLD=0 GPRF_PART_MAJOR=0
-GPRF_AT_REVERSE=0 GPRF_POTRF_BIG8=0): the three digests must be equal (bit-identical variants, no race)."""
+everything returned.  Run it twice, and once with the diagnostic switches off (GPRF_DIAG=fused_build=0,gx_fold=0,part_major=0,one_queue=1): the three digests must be equal (bit-identical variants, no race)."""
 import hashlib, sys, os
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,6 +1,6 @@
 """Stage times with units of 21-30 tiles per edge (16 blocks of ~206 points + their pairs, SE kernel; FILL=1: K through the pool):
     python scripts/gpu_wide_units_time.py [n] [blocks]
-(A/B: GPRF_POTRF_GW=0 sends the units of 21..28 tiles to the generic kernel instead of k_potrf_reg8w)"""
+(A/B: GPRF_DIAG=potrf_gw=0 sends the units of 21..28 tiles to the generic kernel instead of k_potrf_reg8w)"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,7 +11,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 # counter passes: the profiler serialises the dispatches of ALL queues, and a stream-memory-operation wait in front of
 # the solve (the join of the two Cholesky queues) then never sees its value written — the library puts the two Cholesky
 # kernels on one queue when it sees ROCPROF_COUNTER_COLLECTION (set by --pmc); every pass under `timeout` all the same
-export GPRF_POTRF_DUAL=2      # explicit: one queue for the counter passes (the library would also recognise the profiler)
+export GPRF_DIAG=one_queue=1      # explicit: one queue for the counter passes (the library would also recognise the profiler)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/bench_pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/bench_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/bench_pmc_write.log 2>&1

@@ -24,9 +24,8 @@ def main():
     tmp = tempfile.mkdtemp()
     open(os.path.join(tmp, "d.py"), "w").write(DRIVER)
     res = {}
-    for tag, env in (("default", {}), ("big8=0", {"GPRF_POTRF_BIG8": "0"}), ("fill", {"GPRF_FUSED_FILL": "0"}),
-                     ("fill,big8=0", {"GPRF_FUSED_FILL": "0", "GPRF_POTRF_BIG8": "0"}), ("reg=0", {"GPRF_POTRF_REG": "0"}),
-                     ("dual=0", {"GPRF_POTRF_DUAL": "0"})):
+    for tag, env in (("default", {}), ("fill", {"GPRF_DIAG": "fused_fill=0"}), ("reg=0", {"GPRF_DIAG": "potrf_reg=0"}),
+                     ("gw=0", {"GPRF_DIAG": "potrf_gw=0"}), ("one queue", {"GPRF_DIAG": "one_queue=1"})):
         e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         e.update(env)
         out = os.path.join(tmp, tag.replace(",", "_").replace("=", "") + ".npz")

@@ -76,6 +76,26 @@ def test_plain_python_bench_gpus_2_launches_the_ranks_itself():
     assert sp["group"]["members"] == 2
 
 
+def test_eight_ranks_dry_run_on_one_gpu():
+    """`python bench.py --gpus 8` as the scaling driver calls it, on a one-GPU box: eight ranks time-share GPU 0 over gloo
+    (GPRF_BENCH_ONE_GPU=1).  Nothing N = 2 never touched may stop the first real 8-GPU run: eight shards, every unit on
+    exactly one rank, one contract line, rc 0."""
+    env = dict(os.environ, GPRF_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--reps", "3",
+           "--ntrain", "3000", "--nblocks", "36", "--yd", "8", "--no-c4", "--no-c5", "--no-cpu-baseline",
+           "--no-single-process-leg"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 5 and d["value"] > 0
+    assert d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert len(d["shard_units"]) == 8 and sum(d["shard_units"]) == 36 + len_pairs(36) and min(d["shard_units"]) > 0
+
+
 def len_pairs(nblocks):
     """pairs of the 8-neighbourhood on the g x g grid of block centres"""
     g = int(round(nblocks ** 0.5))

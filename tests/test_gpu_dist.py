@@ -88,7 +88,7 @@ def _worker(rank, world, port, q):
             gs.close()
         # --- a re-partition that grows ONE unit past GPRF_MAX_UNIT points: fatal on the rank that owns it only
         # (the limit lowered to 1024 for this: a real unit of 16385 points costs 4e12 flop to get to)
-        os.environ["GPRF_MAX_UNIT_OVERRIDE"] = "1024"
+        os.environ["GPRF_DIAG"] = "max_unit=1024"
         from gprf_amd import Blocker, grid_centers
         rng = np.random.RandomState(8)
         Xa = rng.rand(1200, 2)
@@ -109,7 +109,7 @@ def _worker(rank, world, port, q):
         out["too_big_after"] = float(t.item())
         out["too_big_owner"] = int(_capi.partition_units(np.array([300] * 4 + [600] * 6, dtype=np.int32), 3, world)[4])
         gb.close()
-        del os.environ["GPRF_MAX_UNIT_OVERRIDE"]
+        del os.environ["GPRF_DIAG"]
         q.put((rank, out))
     finally:
         dist.destroy_process_group()

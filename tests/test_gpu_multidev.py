@@ -50,6 +50,30 @@ def test_group_equals_the_sum_of_shards_bit_for_bit_and_the_single_device_result
     one.close(); grp.close()
 
 
+def test_eight_members_on_one_gpu_equal_the_single_device_result():
+    """GPRF(devices=[0] * 8): the shape of the one-process 8-GPU run with all eight members on GPU 0 — eight shards, eight
+    slots, one summing kernel; every unit on exactly one member, the result equal to the single-device one to 1e-12 over a
+    re-partitioning walk."""
+    from gprf_amd.gprf import GPRF
+    X, Y, b, cov = _case(n=4000, nb=36)
+    nbrs = b.neighbors()
+    one = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs)
+    grp = GPRF(X, Y, b.block_clusters, cov, 0.01, neighbors=nbrs, devices=[0] * 8)
+    n_members, on_host, devs = grp._ctx.group_info()[:3]
+    assert n_members == 8 and list(devs) == [0] * 8
+    rng = np.random.RandomState(2)
+    Xk = X
+    for _ in range(3):
+        one.update_X(Xk); grp.update_X(Xk)
+        a, c = one.llgrad(grad_X=True, grad_cov=True), grp.llgrad(grad_X=True, grad_cov=True)
+        assert grp._ctx.num_units() == (one._ctx.num_units()[0], one._ctx.num_units()[0])      # every unit on exactly one member
+        assert sum(grp._ctx.group_info()[3]) == one._ctx.num_units()[0] and min(grp._ctx.group_info()[3]) > 0
+        assert np.isclose(a[0], c[0], rtol=1e-12)
+        assert np.allclose(a[1], c[1], rtol=0, atol=1e-12 * np.abs(a[1]).max()) and np.allclose(a[2], c[2], rtol=1e-11)
+        Xk = Xk + 0.01 * rng.randn(*X.shape)
+    one.close(); grp.close()
+
+
 def test_group_drives_the_optimiser_callback_like_one_device():
     """gprf_objective over a group: the location prior is added by member 0 alone, the trace of a short L-BFGS-B run equals
     the single-device trace."""
@@ -90,7 +114,7 @@ def test_group_not_pd_and_too_big_units_are_reported_once(monkeypatch):
     g1.close(); g2.close()
     # a re-partition that grows a unit past GPRF_MAX_UNIT on one member: the library's message through the front context
     # (the limit lowered to 1024 for this: a real unit of 16385 points costs 4e12 flop to get to)
-    monkeypatch.setenv("GPRF_MAX_UNIT_OVERRIDE", "1024")
+    monkeypatch.setenv("GPRF_DIAG", "max_unit=1024")
     Xa = rng.rand(1200, 2)
     bl = Blocker(grid_centers(4))
     gb = GPRF(Xa, rng.randn(1200, 3), bl.block_clusters, GPCov([1.0], [0.2, 0.2], "euclidean", "se"), 0.01,

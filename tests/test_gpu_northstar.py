@@ -5,7 +5,7 @@ lscale=0.06, obs_std=0.02, with and without the 342 neighbour pairs.  Checks
   * objective and gradient against the oracle on identical inputs.  BASELINE.json's "gradient max-abs error < 1e-8" is
     BELOW the reference path's own rounding on this configuration (the fp64 LAPACK oracle is 1.0-2.1e-8 per unit, 1.05e-7
     on the assembled 342-pair gradient, away from an 80-bit evaluation; max |gradX| ~ 2e5), so what is asserted is (i)
-    closeness to the 80-BIT TRUTH relative to the oracle's own (|GPU - true| <= 1.1 |oracle - true| assembled; per pair
+    closeness to the 80-BIT TRUTH relative to the oracle's own (|GPU - true| <= 0.85 |oracle - true| assembled, 1.15 local; per pair
     unit: pooled maximum, mean ratio and worst ratio, 40 units) and (ii) a bound on |GPU - oracle|, two fp64 paths:
     4e-8 (local GP) / 3e-7 (342 pairs); ll relative 1e-12; gC relative 1e-9 (DESIGN.md section 5);
   * size-independent properties: directional finite difference, Bethe sum rule.
@@ -97,10 +97,15 @@ def test_gradient_against_oracle_and_extended_precision(sdata, local_dist):
           % (local_dist, gmax, e_go, e_gt, e_ot, abs(ll - o_ll) / abs(o_ll), abs(float(ll - t_ll)) / abs(float(t_ll)),
              abs(float(o_ll - t_ll)) / abs(float(t_ll))))
     # (a) as accurate as the reference CPU path.  A maximum over 20000 entries moves by several per cent with any change of a
-    # rounding anywhere; measured: r03 0.98x (local) / 0.74x (342 pairs); r04, row panel as V_jj^T C_jk on the matrix pipe:
-    # 1.07-1.11x / 0.74-0.78x (profiles/r04_numerics*.log) — the explicit 16 x 16 inverse costs the local-only case what the
-    # substitution did not, the assembled north-star gradient stays a quarter closer to the truth than LAPACK
-    assert e_gt <= (1.25 if local_dist == 1.0 else 1.0) * e_ot
+    # rounding anywhere; measured: r03 0.98x (local) / 0.74x (342 pairs); since r04, row panel as V_jj^T C_jk on the matrix
+    # pipe: 1.07-1.11x / 0.74-0.78x (profiles/r04_numerics*.log, r05_numerics.log).  Round 5 tried to buy the local-only case
+    # back and could not without paying elsewhere (a Newton-Schulz step on V_jj changes nothing — the
+    # CORRECTLY ROUNDED inverse gives the same 0.97-0.98 in a numpy emulation; one step of refinement on every panel restores
+    # 1.00x here but costs 12 us of the Cholesky stage and 1.07x on the assembled gradient; on the small units only it costs
+    # nothing and takes the assembled gradient to 1.34x): the bounds are the measured values plus a margin of a few per cent,
+    # and the ABSOLUTE errors are pinned too, so that the trade made in round 4 stays the trade it was
+    assert e_gt <= (1.15 if local_dist == 1.0 else 0.85) * e_ot
+    assert e_gt <= (2.2e-8 if local_dist == 1.0 else 9.5e-8)
     # (b) agreement at the common rounding floor: at most TWICE what round 1 measured on MI355X (1.94e-8 without /
     # 1.52e-7 with the 342 pair units: profiles/r01_final_pytest_gpu.log) — a 2x regression fails
     assert e_go <= (4e-8 if local_dist == 1.0 else 3e-7)
@@ -164,8 +169,10 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
         |oracle - true| (fp64 LAPACK):                     max 2.51e-8 mean 1.53e-8
     (the explicit tile inverse costs ~5 % of accuracy and 8 % of the Cholesky's time less; the device stays closer to the
     truth than LAPACK on average).  The per-unit ratio divides by the oracle's error of THAT unit, which scatters by 3x, so
-    its maximum over 42 units is a tail statistic: 1.67 / 2.02 measured.  Asserted: pooled maximum at most 1.25x the
-    oracle's, mean ratio at most 1.1, no single unit more than 2.5x further from the truth than the oracle is."""
+    its maximum over 42 units is a tail statistic: 1.67 / 2.02 measured.  Asserted (round 5: the measured values plus a small
+    margin, and the absolute errors, so that a further 10-20 % of rounding cannot slip in): pooled maximum at most 1.15x the
+    oracle's and 3.0e-8, mean ratio at most 0.95 and mean error 1.45e-8, no single unit more than 2.2x further from the truth
+    than the oracle is."""
     from ld_truth import unit_llgrad_ld
     g = sdata.build_gprf(local_dist=0.1)
     g.llgrad(grad_X=True)
@@ -192,7 +199,7 @@ def test_pair_units_against_extended_precision_one_by_one(sdata):
     print("pair units vs 80-bit: %d units (m %d..%d)  |gpu-true| max %.3g mean %.3g   |oracle-true| max %.3g mean %.3g   "
           "ratio mean %.2f min %.2f max %.2f" % (len(pick), sizes[pick].min(), sizes[pick].max(), e_gpu.max(), e_gpu.mean(),
                                                  e_orc.max(), e_orc.mean(), ratio.mean(), ratio.min(), ratio.max()))
-    assert e_gpu.max() <= 1.25 * e_orc.max()
-    assert ratio.mean() <= 1.1
-    assert ratio.max() <= 2.5
+    assert e_gpu.max() <= 1.15 * e_orc.max() and e_gpu.max() <= 3.0e-8          # measured 1.06x, 2.66e-8
+    assert ratio.mean() <= 0.95 and e_gpu.mean() <= 1.45e-8                       # measured 0.89, 1.32e-8
+    assert ratio.max() <= 2.2                                                      # measured 2.02
     g.close()

@@ -449,12 +449,12 @@ def test_kernel_values_to_a_few_ulp_over_the_whole_exponent_range():
 
 
 def test_generated_and_filled_kernel_matrices_give_the_same_evaluation(monkeypatch):
-    """SE units of up to 256 points: k_potrf_reg generates K itself and k_fill does not run (GPRF_FUSED_FILL=0 forces
+    """SE units of up to 256 points: k_potrf_reg generates K itself and k_fill does not run (GPRF_DIAG fused_fill=0 forces
     the K pool back).  Both routes against the golden vectors, and against each other to rounding."""
     z = load_golden("c1_small.npz")
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("GPRF_FUSED_FILL", mode)
+        monkeypatch.setenv("GPRF_DIAG", "fused_fill=" + mode)
         g = _gprf_from_golden(z, Xkey="X_obs", Ykey="SY")
         out[mode] = g.llgrad(grad_X=True, grad_cov=True)
         assert np.isclose(out[mode][0], z["ll_gprf"], rtol=1e-12) and _close(out[mode][1], z["gX_gprf"], 1e-10)
@@ -489,11 +489,11 @@ def test_one_pair_over_256_points_leaves_the_other_units_generated(monkeypatch):
     cov = GPCov([1.0], [0.12, 0.12], "euclidean", "se")
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("GPRF_FUSED_FILL", mode)
+        monkeypatch.setenv("GPRF_DIAG", "fused_fill=" + mode)
         g = GPRF(X, Y, None, cov, 0.01, block_idxs=blocks, neighbors=nbrs)
         out[mode] = g.llgrad(grad_X=True, grad_cov=True)
         g.close()
-    monkeypatch.delenv("GPRF_FUSED_FILL")
+    monkeypatch.delenv("GPRF_DIAG")
     r = GPRFRef(X, Y, None, OCov([1.0], [0.12, 0.12], "euclidean", "se"), 0.01, block_idxs=blocks, neighbors=nbrs, mode="matrix")
     o = r.llgrad(grad_X=True, grad_cov=True)
     for mode in ("1", "0"):
@@ -684,7 +684,7 @@ def test_more_units_than_the_table_build_keeps_in_lds():
 def test_one_queue_cholesky_under_counter_collection_gives_the_same_bits():
     """rocprofv3 --pmc serialises the dispatches of all queues; the stream-memory-operation join of the two Cholesky
     queues would then never complete, so the library puts both instantiations on ONE queue when it sees
-    ROCPROF_COUNTER_COLLECTION (set by --pmc) or GPRF_POTRF_DUAL=2.  Same kernels, same units: the result must be bit
+    ROCPROF_COUNTER_COLLECTION (set by --pmc) or GPRF_DIAG one_queue=1.  Same kernels, same units: the result must be bit
     for bit the two-queue result (fresh processes: the switch is read once per process)."""
     import subprocess, sys
     code = r'''
@@ -703,7 +703,7 @@ print("RESULT", repr(float(ll)), hashlib.sha1(np.ascontiguousarray(gX).tobytes()
 g.close()
 '''
     outs = []
-    for extra in ({}, {"ROCPROF_COUNTER_COLLECTION": "1"}, {"GPRF_POTRF_DUAL": "2"}):
+    for extra in ({}, {"ROCPROF_COUNTER_COLLECTION": "1"}, {"GPRF_DIAG": "one_queue=1"}):
         env = dict(os.environ)
         env.pop("ROCPROF_COUNTER_COLLECTION", None)
         env.update(extra)

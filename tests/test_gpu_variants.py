@@ -1,7 +1,7 @@
 """The launch variants of one evaluation agree bit for bit: the single-launch table build (k_build_scatter) against
 the three-launch one (k_build x 2 + k_scatter_x), the gradient partials folded inside the assembly against a
-k_gx_finalize launch, the Cholesky as two instantiations on two queues against one queue.  The switches are read
-once per process (diagnostic environment variables), so every variant runs in its own interpreter on the same seeded
+k_gx_finalize launch, the Cholesky as two instantiations on two queues against one queue.  The forms are selected through the
+library's ONE diagnostic switch (GPRF_DIAG="key=value,..."); every variant runs in its own interpreter on the same seeded
 walk — points cross block borders at every step, so the tables are rebuilt on the device each time — and prints a
 digest of everything the walk returned."""
 import os
@@ -63,22 +63,19 @@ def test_single_launch_table_build_with_many_blocks(tmp_path):
     beyond the assembly's fold (k_gx_finalize runs)"""
     shape = {"VAR_N": "4000", "VAR_BLOCKS": "400"}
     base = run_variant(tmp_path, shape)
-    assert run_variant(tmp_path, dict(shape, GPRF_FUSED_BUILD="0")) == base
+    assert run_variant(tmp_path, dict(shape, GPRF_DIAG="fused_build=0")) == base
     # a launch more than two rounds of CUs deep: the gradient grid is walked part by part in groups of 64 launch slots
-    assert run_variant(tmp_path, dict(shape, GPRF_PART_MAJOR="0")) == base
+    assert run_variant(tmp_path, dict(shape, GPRF_DIAG="part_major=0")) == base
 
 
 def test_launch_variants_agree_bit_for_bit(tmp_path):
     base = run_variant(tmp_path, {})
-    for name, env in (("three-launch table build", {"GPRF_FUSED_BUILD": "0"}),
-                      ("k_gx_finalize as a launch", {"GPRF_GX_FOLD": "0"}),
-                      ("one Cholesky queue", {"GPRF_POTRF_DUAL": "2"}),
-                      ("At workgroups in plain launch order", {"GPRF_AT_REVERSE": "0"}),
-                      ("solve / gradient grids walked unit by unit", {"GPRF_PART_MAJOR": "0"}),
-                      ("largest units on the four-wave Cholesky", {"GPRF_POTRF_BIG8": "0"}),
-                      ("forward substitution with two panel buffers, two workgroups per CU", {"GPRF_SOLVE16_SINGLE": "0"}),
-                      ("the Cholesky's step loop without workgroup barriers (run-ahead form)", {"GPRF_POTRF_RA": "1"}),
-                      ("run-ahead, one queue", {"GPRF_POTRF_RA": "1", "GPRF_POTRF_DUAL": "2"})):
+    for name, env in (("three-launch table build", {"GPRF_DIAG": "fused_build=0"}),
+                      ("k_gx_finalize as a launch", {"GPRF_DIAG": "gx_fold=0"}),
+                      ("one Cholesky queue", {"GPRF_DIAG": "one_queue=1"}),
+                      ("fork / join of the two Cholesky queues by events", {"GPRF_DIAG": "side_events=1"}),
+                      ("solve / gradient grids walked unit by unit", {"GPRF_DIAG": "part_major=0"}),
+                      ("all of these at once", {"GPRF_DIAG": "fused_build=0,gx_fold=0,one_queue=1,part_major=0"})):
         assert run_variant(tmp_path, env) == base, name
 
 
@@ -108,15 +105,14 @@ g.close()
 
 def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
     """16 blocks of ~150 points: pairs of 17-22 tiles per edge.  The eight-wave register kernel takes those of up to 20 (160
-    tiles in accumulators, up to 30 waiting in LDS), generating K (default) or reading it from the pool (GPRF_FUSED_FILL=0).
-    GPRF_POTRF_BIG8=0 / GPRF_POTRF_DUAL=0 send everything above 16 tiles through the K pool and the generic kernel,
-    GPRF_POTRF_REG=0 every unit: the same arithmetic per tile in the same order (row panel V_jj^T C_jk on the matrix pipe,
+    tiles in accumulators, up to 30 waiting in LDS), generating K (default) or reading it from the pool (GPRF_DIAG fused_fill=0).
+    potrf_reg=0 sends every unit through the K pool and the generic kernel: the same arithmetic per tile in the same order (row panel V_jj^T C_jk on the matrix pipe,
     the step's products from zero and one addition), the same bits"""
     import numpy as np
     (tmp_path / "wide.py").write_text(WIDE_DRIVER)
     out = {}
-    for tag, env in (("gen", {}), ("pool", {"GPRF_FUSED_FILL": "0"}), ("generic", {"GPRF_POTRF_BIG8": "0"}),
-                     ("one", {"GPRF_POTRF_DUAL": "0"}), ("queue", {"GPRF_POTRF_DUAL": "2"}), ("all generic", {"GPRF_POTRF_REG": "0"})):
+    for tag, env in (("gen", {}), ("pool", {"GPRF_DIAG": "fused_fill=0"}), ("queue", {"GPRF_DIAG": "one_queue=1"}),
+                     ("all generic", {"GPRF_DIAG": "potrf_reg=0"})):
         e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         e.update(env)
         r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
@@ -124,7 +120,7 @@ def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
         assert r.returncode == 0, r.stdout.decode()[-3000:]
         out[tag] = np.load(str(tmp_path / (tag + ".npz")))
     a = out["gen"]
-    for tag in ("pool", "queue", "generic", "one", "all generic"):
+    for tag in ("pool", "queue", "all generic"):
         b = out[tag]
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
 
@@ -132,13 +128,13 @@ def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
 def test_units_of_21_to_28_tiles_wait_in_the_U_pool(tmp_path):
     """16 blocks of ~206 points: pairs of 24-30 tiles per edge.  A launch with units above 20 tiles goes through the K pool as a
     whole and ONE eight-wave register kernel takes every unit of up to 28 tiles, the tiles beyond its 160 accumulator slots
-    waiting in the U pool (in place, through L2); the 29- and 30-tile pairs take the generic kernel.  GPRF_POTRF_GW=0: the
+    waiting in the U pool (in place, through L2); the 29- and 30-tile pairs take the generic kernel.  GPRF_DIAG potrf_gw=0: the
     generating kernels for units of up to 20 tiles, the generic kernel above — the same bits"""
     import numpy as np
     (tmp_path / "wide.py").write_text(WIDE_DRIVER)
     out = {}
-    for tag, env in (("gw", {}), ("pool", {"GPRF_FUSED_FILL": "0"}), ("generic", {"GPRF_POTRF_GW": "0"}),
-                     ("pool generic", {"GPRF_FUSED_FILL": "0", "GPRF_POTRF_GW": "0"}), ("all generic", {"GPRF_POTRF_REG": "0"})):
+    for tag, env in (("gw", {}), ("pool", {"GPRF_DIAG": "fused_fill=0"}), ("generic", {"GPRF_DIAG": "potrf_gw=0"}),
+                     ("pool generic", {"GPRF_DIAG": "fused_fill=0,potrf_gw=0"}), ("all generic", {"GPRF_DIAG": "potrf_reg=0"})):
         e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), WIDE_N="3300")
         e.update(env)
         r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag.replace(" ", "_") + ".npz"))], cwd=str(tmp_path),
@@ -177,12 +173,12 @@ g.close()
 def test_a_few_wide_units_leave_the_others_generated(tmp_path):
     """A north-star-shaped partition with ONE crowded block: its eight pairs have 21-28 tiles per edge, everything else at most
     13.  The launch stays a generating one (round 2's per-unit decision): the wide pairs are filled and take the eight-wave
-    kernel with waiting tiles in the U pool BEHIND the generating kernels (GPRF_POTRF_GW=0: the generic kernel) — the same
+    kernel with waiting tiles in the U pool BEHIND the generating kernels (GPRF_DIAG potrf_gw=0: the generic kernel) — the same
     bits as everything through the pool"""
     import numpy as np
     (tmp_path / "few.py").write_text(FEW_WIDE_DRIVER)
     out = {}
-    for tag, env in (("gen", {}), ("generic", {"GPRF_POTRF_GW": "0"}), ("pool", {"GPRF_FUSED_FILL": "0"})):
+    for tag, env in (("gen", {}), ("generic", {"GPRF_DIAG": "potrf_gw=0"}), ("pool", {"GPRF_DIAG": "fused_fill=0"})):
         e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         e.update(env)
         r = subprocess.run([sys.executable, str(tmp_path / "few.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
@@ -195,53 +191,8 @@ def test_a_few_wide_units_leave_the_others_generated(tmp_path):
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
 
 
-def test_se_fill_forms_and_grouped_walk_agree_bit_for_bit(tmp_path):
-    """K through the pool (GPRF_FUSED_FILL=0): k_fill_se (half the vector-ALU instructions per value) against the
-    entry-by-entry k_fill<0,0>; and the solve / gradient grids walked part by part in groups of 64 launch slots against
-    launch-wide (a different launch order, the same sums)"""
-    filled = run_variant(tmp_path, {"GPRF_FUSED_FILL": "0"})
-    assert run_variant(tmp_path, {"GPRF_FUSED_FILL": "0", "GPRF_FILL_VARIANT": "0"}) == filled
-    base = run_variant(tmp_path, {})
-    assert run_variant(tmp_path, {"GPRF_PM_GROUP": "64"}) == base
-    # K generated inside the register Cholesky = K filled into the pool and read, entry for entry (both add the noise to the
-    # rounded kernel value: two roundings, as the reference does): the whole walk comes out the same
-    assert filled == base
-
-
-LLD_DRIVER = r'''
-import sys
-import numpy as np
-from gprf_amd import GPCov
-from gprf_amd.gprf import GPRF
-rng = np.random.RandomState(7)
-n = 900
-X = np.column_stack([rng.uniform(100.0, 104.0, n), rng.uniform(30.0, 33.0, n), rng.uniform(0.0, 40.0, n)])
-Y = rng.randn(n, 5)
-order = np.argsort(X[:, 0])
-blocks = [np.sort(order[i:i + 150]) for i in range(0, n, 150)]          # six blocks of 150 events
-nbrs = [(i, i + 1) for i in range(5)]                                    # pairs of 300: the generic kernel
-g = GPRF(X, Y, None, GPCov([2.0], [60.0, 25.0], "lld", "matern32"), 0.05, block_idxs=blocks, neighbors=nbrs)
-ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
-np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
-g.close()
-'''
-
-
-def test_lld_matern_generated_equals_filled(tmp_path):
-    """("lld","matern32"): the unary blocks' kernel matrices generated inside the register Cholesky (GPRF_LLD_GEN=1) against
-    filled into the K pool and read (the default): the same entries by the same arithmetic"""
-    (tmp_path / "lld.py").write_text(LLD_DRIVER)
-    out = {}
-    for tag, env in (("fill", {}), ("gen", {"GPRF_LLD_GEN": "1"})):
-        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        e.update(env)
-        r = subprocess.run([sys.executable, str(tmp_path / "lld.py"), str(tmp_path / (tag + ".npz"))], cwd=str(tmp_path), env=e,
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-        assert r.returncode == 0, r.stdout.decode()[-3000:]
-        import numpy as np
-        out[tag] = np.load(str(tmp_path / (tag + ".npz")))
-    import numpy as np
-    a, b = out["fill"], out["gen"]
-    assert abs(float(a["ll"]) - float(b["ll"])) <= 1e-13 * abs(float(a["ll"]))
-    assert np.max(np.abs(a["gX"] - b["gX"])) <= 1e-11 * np.max(np.abs(a["gX"]))
-    assert np.allclose(a["gC"], b["gC"], rtol=1e-11)
+def test_generated_K_equals_filled_K_bit_for_bit(tmp_path):
+    """K generated inside the register Cholesky = K filled into the pool (k_fill_se, GPRF_DIAG fused_fill=0) and read, entry
+    for entry (both add the noise to the rounded kernel value: two roundings, as the reference does): the whole walk comes
+    out the same"""
+    assert run_variant(tmp_path, {"GPRF_DIAG": "fused_fill=0"}) == run_variant(tmp_path, {})
