@@ -83,6 +83,7 @@ struct gprf_ctx {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // second queue: the Cholesky instantiation that runs beside the main one
+    hipStream_t stream3 = nullptr;        // third queue, LOW priority: the second half of the solve -> At -> gradient pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<uint32_t> d_side;               // fork / join words of the side queue (stream memory operations)
     uint32_t side_seq = 0;
@@ -255,6 +256,7 @@ UnitTab make_tab(gprf_ctx *c) {
     t.max_T = c->max_T;
     t.ids = c->d_ids.p;
     t.n_ids = c->n_local;
+    t.n_launch = c->n_local;
     t.big_list = c->d_big_list.p; t.small_list = c->d_small_list.p; t.ctl = c->d_res.p;
     t.srec = c->d_srec.p; t.big_rec = c->d_big_rec.p; t.small_rec = c->d_small_rec.p;
     t.grid_big = c->grid_big; t.grid_small = c->grid_small;
@@ -637,6 +639,9 @@ int enqueue_partition(gprf_ctx *c, const double *d_X, hipStream_t s) {
     return GPRF_OK;
 }
 
+constexpr int PIPE_DEFAULT_PCT = 0;       // the first (main-queue) part of the split solve -> At -> gradient launches, in per cent (0: off)
+constexpr int PIPE_MIN_UNITS = 128;       // ... which is not worth its fork and join below this many units
+
 // enqueue one evaluation on stream s reading d_X, writing d_out; stop_after < 6 truncates (debug); reblock: first
 // re-partition the points on the device (update_X's block_fn, gprf.py:171-172)
 // host_io: 0 = d_X / d_out are the caller's device buffers; 1 = the zero-copy host-in / host-out form (d_X / d_out are the
@@ -706,6 +711,43 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         launch_big_potrf(ut, pl, kp, s);
     }
     mark();
+    // ---- round 5, measured and left OFF: the three GEMM-shaped stages as TWO pipelines side by side (GPRF_DIAG pipe=<percent>) ----
+    // solve -> At -> gradient are launch-wide stages while the dependency is per unit: each of them ends in a tail of 10-25 us
+    // in which a few long workgroups run on a mostly idle chip, and per-unit flags at agent scope were
+    // measured unaffordable in round 2.  Here the launch order (largest units first) is cut in two: the first part runs its
+    // three kernels on the main queue, the rest runs the SAME three kernels on a third, low-priority queue, fork and join by
+    // stream memory operations (each wait submitted behind its writer).  The same kernel instantiations (UnitTab::n_launch
+    // picks the forms), the same arithmetic per unit: bit-identical to the launch-wide form (tests/test_gpu_variants.py).
+    // Measured on the north-star configuration (profiles/r05_pipeline_ab.txt, ms per step, medians of 7 x 200 steps):
+    // launch-wide 0.3782; cut at 25 % 0.3799, 35 % 0.3780, 50 % 0.3785, 65 % 0.3755, 80 % 0.3816 — nothing.  Why: the three
+    // kernels have different register footprints (157 / 256 / 128 VGPRs: three, two, four workgroups per CU), a slot freed by
+    // one kernel's workgroup does not fit the next kernel's, so the dispatcher keeps filling freed slots with the OTHER
+    // queue's workgroups of the same kernel and the first part's next stage starts no sooner than before; and two half-size
+    // launches lose the launch-wide longest-workgroup-first order that shortened these tails in round 3.
+    const int pipe_pct = diag("pipe", PIPE_DEFAULT_PCT);
+    const bool pipe = pipe_pct > 0 && pipe_pct < 100 && !tm && stop_after >= 5 && do_grad && c->stream3 && c->side_values &&
+                      s == c->stream && !potrf_tool_env() && ut.max_T <= SMALL_MAX_T && ut.n_ids >= PIPE_MIN_UNITS;
+    if (pipe) {
+        int nA = ((ut.n_ids * pipe_pct / 100) + 7) & ~7;
+        if (nA >= ut.n_ids) nA = ut.n_ids - 1;
+        UnitTab ua = ut, ub = ut;
+        ua.n_ids = nA;
+        ub.srec = ut.srec + nA; ub.ids = ut.ids + nA; ub.n_ids = ut.n_ids - nA;
+        hipStream_t s3 = c->stream3;
+        uint32_t *w = c->d_side.p;
+        const uint32_t seq = c->side_seq;
+        HIP_TRY(c, hipStreamWriteValue32(s, w + 3, seq, 0));      // (everything in front — the Cholesky's join included — is done)
+        HIP_TRY(c, hipStreamWaitValue32(s3, w + 3, seq, hipStreamWaitValueGte, 0xffffffffu));
+        launch_solve(ua, pl, kp, s);
+        launch_solve(ub, pl, kp, s3);
+        launch_at(ua, pl, s);
+        launch_at(ub, pl, s3);
+        launch_grad(c->dist_id, c->kern_id, ua, pl, kp, want_gc, !gen, s);
+        launch_grad(c->dist_id, c->kern_id, ub, pl, kp, want_gc, !gen, s3);
+        HIP_TRY(c, hipStreamWriteValue32(s3, w + 4, seq, 0));
+        HIP_TRY(c, hipStreamWaitValue32(s, w + 4, seq, hipStreamWaitValueGte, 0xffffffffu));
+        mark(); mark();
+    } else {
     if (stop_after >= 2) {
         launch_solve(ut, pl, kp, s);
         launch_big_solve(ut, pl, s);
@@ -713,8 +755,9 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     if (stop_after >= 3) launch_at(ut, pl, s);
     mark();
+    if (do_grad) launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
+    }
     if (do_grad) {
-        launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
         // k_gx_finalize is a launch of its own for sums the assembly can do on the way (10 us of a 430 us evaluation) —
         // up to GX_FOLD_MAX_UNITS units; beyond that the assembly's single summing workgroup would walk every unit's
         // partials itself (C4: 106 us against 20).  The per-unit gradient (gprf_debug_fetch) is then made on demand.
@@ -1108,6 +1151,12 @@ int gprf_create(gprf_ctx **out, int32_t n, int32_t dx, int32_t dy, int32_t dist_
         return create_fail(GPRF_ERR_HIP, "could not create the side stream / its events");
     }
     {
+        // (optional: without it the evaluation keeps its launch-wide stage boundaries)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, least) != hipSuccess) { c->stream3 = nullptr; (void)hipGetLastError(); }
+    }
+    {
         int can = 0;
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
         if (diag("side_events", 0)) can = 0;      // diagnostics: force events
@@ -1291,6 +1340,7 @@ int gprf_destroy(gprf_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GPRF_OK;

@@ -47,6 +47,9 @@ struct UnitTab {
     const int32_t *upt;      // [total padded rows] global point index of each unit row; rows >= m are NOT written
     const int32_t *ids;      // the local unit ids in launch order (largest first at the last host build) ...
     int n_ids;               // ... and how many
+    int n_launch;            // the evaluation's WHOLE launch (= n_ids unless this table is one part of a split launch: the
+                             // pipelined halves of enqueue_eval): what picks a kernel FORM, so that a unit's arithmetic does not
+                             // depend on how the launch was split
     int n_units;
     int max_T;               // launch-wide bound on mp/16 (the largest unit at the last synchronised build)
     // the Cholesky's two launch lists, built on the device with the tables (k_build): units of more than / at most

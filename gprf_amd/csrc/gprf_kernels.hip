@@ -4253,12 +4253,12 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     // single-unit latency matters while the launch is about one workgroup-round deep (sharded runs); beyond
     // that the wide form's operand reuse wins (C3 on one GPU: 55 vs 58 us, C4: 324 vs 429 us)
     const int cus = device_cus();
-    if (ut.n_ids <= cus) {
+    if (ut.n_launch <= cus) {
         hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
         return;
     }
     // ONE round of at most two workgroups per CU: the second resident of a CU in ASCENDING size (largest with smallest)
-    const int first_round = (ut.max_T <= 16 && ut.n_ids <= 2 * cus) ? cus : 0;
+    const int first_round = (ut.max_T <= 16 && ut.n_ids > cus && ut.n_ids <= 2 * cus) ? cus : 0;
     hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round);
 }
 

@@ -66,6 +66,19 @@ def test_single_launch_table_build_with_many_blocks(tmp_path):
     assert run_variant(tmp_path, dict(shape, GPRF_DIAG="fused_build=0")) == base
     # a launch more than two rounds of CUs deep: the gradient grid is walked part by part in groups of 64 launch slots
     assert run_variant(tmp_path, dict(shape, GPRF_DIAG="part_major=0")) == base
+    # solve -> At -> gradient as two pipelines side by side (off by default: measured no faster) against launch-wide stages
+    assert run_variant(tmp_path, dict(shape, GPRF_DIAG="pipe=50")) == base
+    assert run_variant(tmp_path, dict(shape, GPRF_DIAG="pipe=20")) == base
+
+
+def test_pipelined_stages_equal_launch_wide_stages_bit_for_bit(tmp_path):
+    """The north-star shape's unit count (100 blocks + 342 pairs): the split solve -> At -> gradient launches — main queue /
+    low-priority queue, cut at 50 %, 25 % and 75 % of the launch order — against the launch-wide form (the default: the split
+    was measured no faster, profiles/r05_pipeline_ab.txt) and against it with one Cholesky queue and the unit-by-unit walk."""
+    shape = {"VAR_N": "5000", "VAR_BLOCKS": "100"}
+    base = run_variant(tmp_path, shape)
+    for d in ("pipe=50", "pipe=25", "pipe=75", "one_queue=1,part_major=0"):
+        assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
 def test_launch_variants_agree_bit_for_bit(tmp_path):
