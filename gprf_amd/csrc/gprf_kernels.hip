@@ -2427,8 +2427,12 @@ __device__ __forceinline__ double row16_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // HAVEK (SE only): the k values of strictly-lower tiles are read back from the K pool; false = K was never written
 // (k_potrf_reg<.,.,true> generated it on the fly): they are re-evaluated like the diagonal tiles' ones.
-template <int DIST, int KERN, bool HAVEK, int FAST>
+// BIG (round 5): the units of more than 1024 points only — their M tiles were made by k_big_gemm (mode 2, 128 x 128 tiles at
+// four times this kernel's flops per byte) and wait in the unit's region of the K pool: the chunk loop is skipped, the
+// accumulators are loaded, the reductions are the same code.  The plain instantiations leave those units alone.
+template <int DIST, int KERN, bool HAVEK, int FAST, bool BIG = false>
 __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
+    static_assert(!(BIG && HAVEK), "the big units' K region holds M: their kernel values are re-evaluated");
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
     // reductions at the end find them in LDS instead of starting with exposed global loads
@@ -2442,6 +2446,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
     int u = ur.u;
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
+    if (BIG != (T > SMALL_MAX_T)) return;      // (uniform) the other instantiation's units
     int TB = (T + 3) >> 2;
     // block pair index -> (JB, IB >= JB), enumerated over the launch-wide TBm
     int JB = 0, rem = bp;
@@ -2575,12 +2580,22 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
     // (bottom-left) block pair -> Pools::dbg[u][0..3] / [4..7]
     unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
-    fetch0(0);
-    if (nch > 1) fetch1(1);
+    if constexpr (BIG) {
+        const double *__restrict__ Mp = pl.K + ur.mat_off;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (need[jj]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[jj][q] = Mp[(size_t)(16 * I + lg + 4 * q) * mp + 16 * (J0 + jj) + lr];
+            }
+    } else {
+        fetch0(0);
+        if (nch > 1) fetch1(1);
+    }
 #ifdef GPRF_PROFILE
     unsigned long long tm1 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int c = 0; c < nch; c += 2) {
+    for (int c = 0; !BIG && c < nch; c += 2) {
         step(c, pre0, true);
         if (c + 1 < nch) step(c + 1, pre1, false);
     }
@@ -3088,17 +3103,27 @@ __device__ __forceinline__ double *big_vkk(const Pools &pl, const BigUnit &b, in
 }
 
 // acc[jt] += sum_{k < kn} SA[k][lr] * SB[k][16 jt + lr-th column]  for this wave's 16 output rows: SA points at the wave's
-// first column of the k x 64 operand (leading dimension lda), SB at the other operand's block (ldb); nj column tiles
+// first column of the k x 64 operand (leading dimension lda), SB at the other operand's block (ldb); nj column tiles.
+// kn <= 64, a multiple of 16.  Every operand value of the block product is requested BEFORE the first MFMA (80 loads in
+// flight per lane): round 4's loop asked for a k-step's five values, waited, issued four MFMAs, sixteen times over — sixteen
+// exposed L2 round trips per block product, and these kernels run between the launches of a 64-row step, where nothing hides them.
 __device__ __forceinline__ void big_block_mma(const double *__restrict__ SA, int lda, const double *__restrict__ SB, int ldb, int kn,
                                               int nj, int lane, d4 (&acc)[4]) {
     int lr = lane & 15, lg = lane >> 4;
     const double *pa = SA + (size_t)lg * lda + lr;
     const double *pb = SB + (size_t)lg * ldb + lr;
-    for (int s = 0; s < (kn >> 2); ++s) {
-        double a = pa[(size_t)(4 * s) * lda];
+    double a[16], bv[16][4];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-            if (jt < nj) acc[jt] = mfma(a, pb[(size_t)(4 * s) * ldb + 16 * jt], acc[jt]);
+    for (int s = 0; s < 16; ++s) {
+        const bool ok = 4 * s < kn;
+        a[s] = ok ? pa[(size_t)(4 * s) * lda] : 0.0;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) bv[s][jt] = (ok && jt < nj) ? pb[(size_t)(4 * s) * ldb + 16 * jt] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = mfma(a[s], bv[s][jt], acc[jt]);
     }
 }
 
@@ -3133,60 +3158,126 @@ __global__ __launch_bounds__(256) void k_big_init(UnitTab ut, Pools pl, int nbma
     }
 }
 
-// the diagonal block of block row kb: upper Cholesky in LDS (row by row: pivot, scaled row, rank-1 update of the rows below),
-// its inverse by back substitution (one column per thread), the log-determinant's share
+// the diagonal block of block row kb: upper Cholesky and its inverse, in 16 x 16 tiles — the small kernels' arithmetic on a
+// 4 x 4 tile grid in LDS.  Step j: wave 0 factors tile (j, j) (diag_factor16_ldl: the root-free pivot chain) and inverts it
+// (the column operations of tile_inverse); the row panel U_jk = V_jj^T C_jk and the trailing tiles C_ik -= U_ji^T U_jk are
+// four MFMAs each, dealt over the four waves.  The inverse V = U^-1 tile by tile: V_jk = -V_jj sum_{l = j+1..k} U_jl V_lk, by
+// distance from the diagonal (three rounds).  ~15 us per block.  (Round 4's form — one pivot at a time over the whole block with
+// three workgroup barriers each, the inverse by per-thread back substitution — took ~100 us, a sixth of the blocked
+// Cholesky's time at n = 10000; two one-wave forms tried on the way, the block in LDS or a column per lane in registers with
+// v_readlane multipliers, took 200 and 57 us.)
 __global__ __launch_bounds__(256) void k_big_diag(UnitTab ut, Pools pl, int kb) {
-    __shared__ double A[BIGB][BIGB + 1], Vl[BIGB][BIGB + 1];
+    constexpr int LDA = BIGB + 16;           // = 16 mod 32 doubles: the k-major MFMA operand reads are conflict free
+    __shared__ double A[BIGB * LDA];         // the block, row-major: becomes U_kk
+    __shared__ double Vl[BIGB * LDA];        // V = U_kk^-1
+    __shared__ double Vt[4 * 256];           // the diagonal tiles' inverses V_jj, row-major
+    __shared__ double piv[BIGB];             // U's diagonal
     __shared__ int s_bad;
-    __shared__ double s_log[4];
     BigUnit b;
     if (!big_unit(ut, blockIdx.x, kb, &b)) return;
-    const int t = threadIdx.x, n = big_rows(b, kb);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int n = big_rows(b, kb);
     const size_t mp = (size_t)b.mp;
     double *U = pl.U + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * kb;
+    for (int e = t; e < BIGB * BIGB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        A[i * LDA + j] = (i < n && j < n) ? U[(size_t)i * mp + j] : ((i == j) ? 1.0 : 0.0);      // identity padding
+        Vl[i * LDA + j] = 0.0;
+    }
     if (t == 0) s_bad = 0;
-    for (int e = t; e < BIGB * BIGB; e += 256) {
-        int i = e >> 6, j = e & 63;
-        A[i][j] = (i < n && j < n && j >= i) ? U[(size_t)i * mp + j] : 0.0;
-    }
     __syncthreads();
-    for (int p = 0; p < n; ++p) {
-        __syncthreads();       // the rank-1 update of the step before is complete
-        double d = A[p][p];
-        if (!(d > 0.0)) {      // (uniform) a non-positive or NaN pivot: report the first, leave garbage
-            if (t == 0 && s_bad == 0) s_bad = BIGB * kb + p + 1;
+    for (int j = 0; j < 4; ++j) {
+        if (wave == 0) {
+            double s16[16], dk, rdk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s16[r] = A[(16 * j + r) * LDA + 16 * j + lr];
+            const int bad = diag_factor16_ldl<NoEarly, false>(s16, lr, &dk, &rdk, nullptr);
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) A[(16 * j + i) * LDA + 16 * j + lr] = (lr >= i) ? s16[i] : 0.0;
+                piv[16 * j + lr] = dk;
+                if (bad && lane == 0 && s_bad == 0) s_bad = BIGB * kb + 16 * j + bad;
+            }
+            double v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                int lrc = lr;
+                asm volatile("" : "+v"(lrc));
+                v[c] = (c == lrc) ? 1.0 : 0.0;
+            }
+            dpp_src_ready(rdk);
+            static_for<0, 16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                v[k] *= bcast16<k>(rdk);
+                dpp_src_ready(s16[k]);
+                static_for<k + 1, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    fnma_bcast16<i>(v[i], s16[k], v[k]);
+                });
+            });
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    Vt[j * 256 + lr * 16 + c] = v[c];
+                    Vl[(16 * j + lr) * LDA + 16 * j + c] = v[c];
+                }
+            }
         }
-        double dd = sqrt(d);
-        __syncthreads();       // everybody has read the pivot before its owner replaces it by its root
-        if (t == p) A[p][p] = dd;
-        else if (t > p && t < n) A[p][t] = A[p][t] / dd;
         __syncthreads();
-        int j = t & 63;
-        for (int i = p + 1 + (t >> 6); i < n; i += 4)
-            if (j >= i && j < n) A[i][j] = fma(-A[p][i], A[p][j], A[i][j]);
-    }
-    __syncthreads();
-    for (int e = t; e < BIGB * BIGB; e += 256) {
-        int i = e >> 6, j = e & 63;
-        if (i < n && j < n) U[(size_t)i * mp + j] = A[i][j];      // (zeros below the diagonal)
-        Vl[i][j] = 0.0;
-    }
-    __syncthreads();
-    if (t < n) {      // column t of V = U^-1: back substitution
-        const int c = t;
-        Vl[c][c] = 1.0 / A[c][c];
-        for (int i = c - 1; i >= 0; --i) {
-            double sum = 0.0;
-            for (int k = i + 1; k <= c; ++k) sum = fma(A[i][k], Vl[k][c], sum);
-            Vl[i][c] = -sum / A[i][i];
+        {   // row panel: U_jk = V_jj^T C_jk
+            const int k = j + 1 + wave;
+            if (k < 4) {
+                d4 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r = mfma(Vt[j * 256 + (4 * q + lg) * 16 + lr], A[(16 * j + 4 * q + lg) * LDA + 16 * k + lr], r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[(16 * j + lg + 4 * q) * LDA + 16 * k + lr] = r[q];
+            }
         }
+        __syncthreads();
+        {   // trailing tiles (i, k), j < i <= k: a step's products from zero, then one subtraction
+            int e = 0;
+            for (int i = j + 1; i < 4; ++i)
+                for (int k = i; k < 4; ++k, ++e)
+                    if ((e & 3) == wave) {
+                        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc = mfma(A[(16 * j + 4 * q + lg) * LDA + 16 * i + lr], A[(16 * j + 4 * q + lg) * LDA + 16 * k + lr], acc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) A[(16 * i + lg + 4 * q) * LDA + 16 * k + lr] -= acc[q];
+                    }
+        }
+        __syncthreads();
     }
-    double lg2 = 0.0;
-    if (t < 64) lg2 = (t < n) ? log(A[t][t]) : 0.0;
-    __syncthreads();
+    // V's off-diagonal tiles by distance d from the diagonal: V_jk = -V_jj (sum_l U_jl V_lk), l = j+1 .. k
+    for (int d = 1; d < 4; ++d) {
+        const int jj = wave, kk = wave + d;
+        if (kk < 4) {
+            d4 T = {0.0, 0.0, 0.0, 0.0};
+            for (int l = jj + 1; l <= kk; ++l) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)      // SA^T = U_jl: a transposed read
+                    T = mfma(A[(16 * jj + lr) * LDA + 16 * l + 4 * q + lg], Vl[(16 * l + 4 * q + lg) * LDA + 16 * kk + lr], T);
+            }
+            d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R = mfma(Vt[jj * 256 + lr * 16 + 4 * q + lg], T[q], R);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Vl[(16 * jj + lg + 4 * q) * LDA + 16 * kk + lr] = -R[q];
+        }
+        __syncthreads();
+    }
     double *Vk = big_vkk(pl, b, kb);
-    for (int e = t; e < BIGB * BIGB; e += 256) Vk[e] = Vl[e >> 6][e & 63];
+    for (int e = t; e < BIGB * BIGB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        const bool in = i < n && j < n;
+        if (in) U[(size_t)i * mp + j] = (j >= i) ? A[i * LDA + j] : 0.0;      // (zeros below the diagonal)
+        Vk[e] = (in && j >= i) ? Vl[i * LDA + j] : 0.0;
+    }
     if (t < 64) {
+        double lg2 = (t < n) ? log(piv[t]) : 0.0;
         for (int off = 32; off >= 1; off >>= 1) lg2 += shfl_xor_d(lg2, off);
         if (t == 0) {
             pl.logdet[b.u] = (kb == 0 ? 0.0 : pl.logdet[b.u]) + 2.0 * lg2;
@@ -3194,7 +3285,6 @@ __global__ __launch_bounds__(256) void k_big_diag(UnitTab ut, Pools pl, int kb) 
             if (s_bad && pl.info[b.u] == 0) pl.info[b.u] = s_bad;
         }
     }
-    (void)s_log;
 }
 
 // X = V_kk^T B in place for a set of blocks of block row kb.  which = 0: the Cholesky's row panel, blocks j = kb+1 .. of U;
@@ -3245,7 +3335,9 @@ __global__ __launch_bounds__(256) void k_big_apply(UnitTab ut, Pools pl, int kb,
 // C -= SA^T SB over a set of blocks behind block row kb.  which = 0: the Cholesky's trailing blocks (i, j), kb < i <= j:
 // C = U_ij, SA = U_ki, SB = U_kj; which = 1: the substitution's rows i > kb: C = W_ic (c <= kb) or the rows of Z,
 // SA = U_ki, SB = W_kc or Z_k.  blockIdx.x enumerates the launch-wide block grid (r = nbmax - kb - 1 rows behind kb).
-__global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb, int which, int nbmax) {
+// i_end: only block rows i < i_end (round 5: the rows INSIDE the current super-block of BG_SUPER block rows; everything
+// behind it takes the super-block's whole contribution at once, k_big_gemm)
+__global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb, int which, int nbmax, int i_end) {
     BigUnit b;
     if (!big_unit(ut, blockIdx.y, kb, &b)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3263,7 +3355,7 @@ __global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb
         while (x >= r - di) { x -= r - di; ++di; }      // row di of the upper block triangle, x columns in
         i = kb + 1 + di;
         int j = i + x;
-        if (j >= b.nb) return;
+        if (j >= b.nb || i >= i_end) return;
         C = pl.U + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * j;
         SB = Uk + (size_t)BIGB * j;
         ldc = b.mp;
@@ -3272,7 +3364,7 @@ __global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb
         const int ncol = kb + 2;
         i = kb + 1 + (int)blockIdx.x / ncol;
         int c = (int)blockIdx.x % ncol;
-        if (i >= b.nb) return;
+        if (i >= b.nb || i >= i_end) return;
         if (c <= kb) {
             C = pl.W + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * c;
             SB = pl.W + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * c;
@@ -3299,15 +3391,21 @@ __global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb
             }
 }
 
-// ||Z[:, 16 cb : 16 cb + 16]||_F^2 per column block (the small kernels' zzpart), fixed order
-__global__ __launch_bounds__(256) void k_big_zz(UnitTab ut, Pools pl) {
+// ||Z[:, 16 cb : 16 cb + 16]||_F^2 per column block (the small kernels' zzpart), fixed order: BIG_ZZ_PARTS workgroups per unit sum
+// a row range each into a scratch slot (the unit's region of rowpart, which the gradient kernel overwrites later); a second,
+// one-wave launch folds the slots in slot order (round 4's single workgroup per unit walked the 10000-point unit's 5 MB
+// alone: 0.86 ms)
+constexpr int BIG_ZZ_PARTS = 64;
+__global__ __launch_bounds__(256) void k_big_zz(UnitTab ut, Pools pl, int tbs) {
     __shared__ double red[256];
     BigUnit b;
-    if (!big_unit(ut, blockIdx.x, 0, &b)) return;
+    if (!big_unit(ut, blockIdx.y, 0, &b)) return;
     const int t = threadIdx.x, col = t & 63, r0 = t >> 6;
     const double *Z = pl.Z + b.row_off * YPAD;
+    const int per = ((b.mp + BIG_ZZ_PARTS - 1) / BIG_ZZ_PARTS + 3) & ~3;
+    const int lo = per * (int)blockIdx.x, hi = lo + per < b.mp ? lo + per : b.mp;
     double s = 0.0;
-    for (int row = r0; row < b.mp; row += 4) {
+    for (int row = lo + r0; row < hi; row += 4) {
         double z = Z[(size_t)row * YPAD + col];
         s = fma(z, z, s);
     }
@@ -3318,8 +3416,182 @@ __global__ __launch_bounds__(256) void k_big_zz(UnitTab ut, Pools pl) {
     if (t < 4) {
         double v = 0.0;
         for (int k = 0; k < 16; ++k) v += red[16 * t + k];
+        pl.rowpart[b.row_off * (size_t)tbs * XPAD + 4 * blockIdx.x + t] = v;
+    }
+}
+__global__ __launch_bounds__(64) void k_big_zz_fold(UnitTab ut, Pools pl, int tbs) {
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.x, 0, &b)) return;
+    const int t = threadIdx.x;
+    if (t < 4) {
+        const double *part = pl.rowpart + b.row_off * (size_t)tbs * XPAD;
+        double v = 0.0;
+        for (int k = 0; k < BIG_ZZ_PARTS; ++k) v += part[4 * k + t];
         pl.zzpart[(size_t)b.u * 4 + t] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_big_gemm (round 5): the blocked path's trailing updates as an LDS-staged MFMA GEMM.
+// A right-looking factorisation in 64-row steps updates the whole trailing matrix once per step with K = 64: one read and one
+// write of every trailing entry per 64 rows — at n = 10000 that is 125 GB through L2 / HBM for 3.3e11 flop, and round 4's
+// blocked path ran at 8-12 TFLOP/s because of it.  Now the 64-row steps only run INSIDE a super-block of BG_SUPER = 4 block
+// rows (k_big_diag / k_big_apply / k_big_update with i_end); what lies behind the super-block takes its 256 rows' contribution
+// in ONE pass,  C -= A^T B  with A, B the super-block's rows of U (or W / Z) — the file's one MFMA form, D += SA^T SB with k the
+// slow index, so nothing is transposed:
+//   * one workgroup = one 128 x 128 tile of C, four waves of 64 x 64 (16 accumulator tiles each);
+//   * the operands' 8-row chunks [8 x 128 | 8 x 128] go global -> registers -> LDS (pitch 144: the k-major operand reads are
+//     conflict free), two register sets and two LDS buffers deep, one LDS-only barrier per chunk; a wave reads 4 + 4 operand
+//     values per k-step of 16 MFMAs;
+//   * a tile's products are summed from zero and enter C with one subtraction (the hierarchical accumulation of the small
+//     kernels).
+// mode 0: the Cholesky's trailing tiles (upper triangle behind the super-block, 128-tile (di, dj), dj >= di);
+// mode 1: the substitution's rows behind the super-block, [W columns up to the super-block's end | Z];
+// mode 2: M = At^T At - dy W^T W on the lower triangle of 128-tiles, WRITTEN to the unit's region of the K pool (nobody reads
+//         K there any more) for k_mgrad<.., BIG> to reduce — the gradient kernel's own 64 x 64 block pairs re-read W at 8 flop
+//         per byte: 49 of the 120 ms of the 10000-point unit.
+// ------------------------------------------------------------------------------------------------
+constexpr int BGT = 128, BG_LD = 144, BG_KC = 8, BG_SUPER = 4;
+
+struct BgOp { const double *A, *B; int lda, ldb, K; double scale; };
+
+// acc[ii][jj] += scale * sum_k A[k][64 wr + 16 ii + .] B[k][64 wc + 16 jj + .]   (wr, wc = this wave's quadrant)
+__device__ __forceinline__ void bg_accumulate(const BgOp &op, int a_ext, int b_ext, double *sm, d4 (&acc)[4][4], bool compute) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    // staging roles: waves 0 / 1 the A chunk's columns 0..63 / 64..127, waves 2 / 3 the B chunk's
+    const bool isB = wave >= 2;
+    const int col = 64 * (wave & 1) + lane;
+    const bool col_ok = col < (isB ? b_ext : a_ext);
+    const double *src0 = (isB ? op.B : op.A) + col;
+    const int ld = isB ? op.ldb : op.lda;
+    const int nch = (op.K + BG_KC - 1) / BG_KC;
+    double pre0[BG_KC], pre1[BG_KC];
+    auto fetch = [&](int c, double (&pre)[BG_KC]) {
+        const double *src = src0 + (size_t)(BG_KC * c) * ld;
+#pragma unroll
+        for (int e = 0; e < BG_KC; ++e) pre[e] = (col_ok && BG_KC * c + e < op.K) ? src[(size_t)e * ld] : 0.0;
+    };
+    auto step = [&](int c, double (&pre)[BG_KC]) {
+        double *buf = sm + (c & 1) * (2 * BG_KC * BG_LD);
+        double *dst = buf + (isB ? BG_KC * BG_LD : 0) + col;
+#pragma unroll
+        for (int e = 0; e < BG_KC; ++e) dst[e * BG_LD] = pre[e];
+        lds_barrier();
+        if (c + 2 < nch) fetch(c + 2, pre);
+        if (compute) {
+            const double *pa = buf + lg * BG_LD + 64 * (wave >> 1) + lr;
+            const double *pb = buf + BG_KC * BG_LD + lg * BG_LD + 64 * (wave & 1) + lr;
+#pragma unroll
+            for (int s = 0; s < BG_KC / 4; ++s) {
+                double a[4], bb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = pa[(4 * s) * BG_LD + 16 * q] * op.scale;
+                    bb[q] = pb[(4 * s) * BG_LD + 16 * q];
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = mfma(a[ii], bb[jj], acc[ii][jj]);
+            }
+        }
+    };
+    if (nch > 0) fetch(0, pre0);
+    if (nch > 1) fetch(1, pre1);
+    for (int c = 0; c < nch; c += 2) {
+        step(c, pre0);
+        if (c + 1 < nch) step(c + 1, pre1);
+    }
+    lds_barrier();      // (a second call reuses the buffers)
+}
+
+__global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int mode, int sb0, int sb1, int ntmax, double dy) {
+    __shared__ double sm[2 * 2 * BG_KC * BG_LD];
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, 0, &b)) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int mp = b.mp;
+    const size_t mps = (size_t)mp;
+    const int r0 = BIGB * sb1, k0 = BIGB * sb0;
+    double *U = pl.U + b.mat_off, *W = pl.W + b.mat_off;
+    int i0, j0, ldc, a_ext, b_ext;
+    double *C;
+    bool skip = false;      // this wave's quadrant is not wanted
+    d4 acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = d4{0.0, 0.0, 0.0, 0.0};
+    int x = blockIdx.x;
+    if (mode == 0) {
+        if (r0 >= mp) return;
+        const int nt = (mp - r0 + BGT - 1) / BGT;
+        int di = 0;
+        while (x >= ntmax - di) { x -= ntmax - di; ++di; }
+        const int dj = di + x;
+        if (dj >= nt) return;
+        i0 = r0 + BGT * di; j0 = r0 + BGT * dj;
+        a_ext = mp - i0 < BGT ? mp - i0 : BGT; b_ext = mp - j0 < BGT ? mp - j0 : BGT;
+        skip = di == dj && (wave >> 1) == 1 && (wave & 1) == 0;      // below the diagonal
+        BgOp op{U + (size_t)k0 * mps + i0, U + (size_t)k0 * mps + j0, mp, mp, r0 - k0, 1.0};
+        bg_accumulate(op, a_ext, b_ext, sm, acc, !skip);
+        C = U + (size_t)i0 * mps + j0; ldc = mp;
+    } else if (mode == 1) {
+        if (r0 >= mp) return;
+        const int nt = (mp - r0 + BGT - 1) / BGT, ncol = sb1 / 2 + 1;
+        const int di = x / ncol, c = x - di * ncol;
+        if (di >= nt) return;
+        i0 = r0 + BGT * di;
+        a_ext = mp - i0 < BGT ? mp - i0 : BGT;
+        BgOp op{U + (size_t)k0 * mps + i0, nullptr, mp, mp, r0 - k0, 1.0};
+        if (c < ncol - 1) {
+            j0 = BGT * c; b_ext = BGT;
+            op.B = W + (size_t)k0 * mps + j0;
+            C = W + (size_t)i0 * mps + j0; ldc = mp;
+        } else {
+            j0 = 0; b_ext = YPAD;
+            op.B = pl.Z + (b.row_off + (size_t)k0) * YPAD; op.ldb = YPAD;
+            C = pl.Z + (b.row_off + (size_t)i0) * YPAD; ldc = YPAD;
+            skip = (wave & 1) == 1;
+        }
+        bg_accumulate(op, a_ext, b_ext, sm, acc, !skip);
+    } else {
+        const int nt = (mp + BGT - 1) / BGT;
+        int tj = 0;
+        while (x >= ntmax - tj) { x -= ntmax - tj; ++tj; }
+        const int ti = tj + x;      // I >= J
+        if (ti >= nt) return;
+        i0 = BGT * ti; j0 = BGT * tj;
+        a_ext = mp - i0 < BGT ? mp - i0 : BGT; b_ext = mp - j0 < BGT ? mp - j0 : BGT;
+        skip = ti == tj && (wave >> 1) == 0 && (wave & 1) == 1;      // above the diagonal
+        const double *At = pl.At + b.row_off * YPAD;
+        BgOp opa{At + i0, At + j0, mp, mp, YPAD, 1.0};
+        bg_accumulate(opa, a_ext, b_ext, sm, acc, !skip);
+        // W is lower triangular: its columns of tile I are zero above row i0
+        BgOp opw{W + (size_t)i0 * mps + i0, W + (size_t)i0 * mps + j0, mp, mp, mp - i0, -dy};
+        bg_accumulate(opw, a_ext, b_ext, sm, acc, !skip);
+        C = pl.K + b.mat_off + (size_t)i0 * mps + j0; ldc = mp;
+    }
+    if (skip) return;
+    const int rbase = 64 * (wave >> 1), cbase = 64 * (wave & 1);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int cc = cbase + 16 * jj + lr;
+            if (cc < b_ext) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rr = rbase + 16 * ii + lg + 4 * q;
+                    if (rr < a_ext) {
+                        double *cp = C + (size_t)rr * ldc + cc;
+                        *cp = mode == 2 ? acc[ii][jj][q] : *cp - acc[ii][jj][q];
+                    }
+                }
+            }
+        }
 }
 
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
@@ -3327,12 +3599,18 @@ void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipS
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
     hipLaunchKernelGGL(k_big_init, dim3(nbmax * nbmax + nbmax, ut.n_ids), blk, 0, s, ut, p, nbmax, kp.dy);
-    for (int kb = 0; kb < nbmax; ++kb) {
-        hipLaunchKernelGGL(k_big_diag, dim3(ut.n_ids), blk, 0, s, ut, p, kb);
-        const int r = nbmax - kb - 1;
-        if (r > 0) {
-            hipLaunchKernelGGL(k_big_apply, dim3(r, ut.n_ids), blk, 0, s, ut, p, kb, 0);
-            hipLaunchKernelGGL(k_big_update, dim3(r * (r + 1) / 2, ut.n_ids), blk, 0, s, ut, p, kb, 0, nbmax);
+    for (int sb0 = 0; sb0 < nbmax; sb0 += BG_SUPER) {
+        const int sb1 = sb0 + BG_SUPER < nbmax ? sb0 + BG_SUPER : nbmax;
+        for (int kb = sb0; kb < sb1; ++kb) {
+            hipLaunchKernelGGL(k_big_diag, dim3(ut.n_ids), blk, 0, s, ut, p, kb);
+            const int r = nbmax - kb - 1, rin = sb1 - kb - 1;
+            if (r > 0) hipLaunchKernelGGL(k_big_apply, dim3(r, ut.n_ids), blk, 0, s, ut, p, kb, 0);
+            // the rows inside the super-block: the first rin rows of the upper block triangle behind kb
+            if (rin > 0) hipLaunchKernelGGL(k_big_update, dim3(rin * r - rin * (rin - 1) / 2, ut.n_ids), blk, 0, s, ut, p, kb, 0, nbmax, sb1);
+        }
+        if (sb1 < nbmax) {
+            const int nt = (BIGB * (nbmax - sb1) + BGT - 1) / BGT;
+            hipLaunchKernelGGL(k_big_gemm, dim3(nt * (nt + 1) / 2, ut.n_ids), blk, 0, s, ut, p, 0, sb0, sb1, nt, 0.0);
         }
     }
 }
@@ -3341,12 +3619,21 @@ void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
-    for (int kb = 0; kb < nbmax; ++kb) {
-        hipLaunchKernelGGL(k_big_apply, dim3(kb + 2, ut.n_ids), blk, 0, s, ut, p, kb, 1);
-        const int r = nbmax - kb - 1;
-        if (r > 0) hipLaunchKernelGGL(k_big_update, dim3(r * (kb + 2), ut.n_ids), blk, 0, s, ut, p, kb, 1, nbmax);
+    for (int sb0 = 0; sb0 < nbmax; sb0 += BG_SUPER) {
+        const int sb1 = sb0 + BG_SUPER < nbmax ? sb0 + BG_SUPER : nbmax;
+        for (int kb = sb0; kb < sb1; ++kb) {
+            hipLaunchKernelGGL(k_big_apply, dim3(kb + 2, ut.n_ids), blk, 0, s, ut, p, kb, 1);
+            const int rin = sb1 - kb - 1;
+            if (rin > 0) hipLaunchKernelGGL(k_big_update, dim3(rin * (kb + 2), ut.n_ids), blk, 0, s, ut, p, kb, 1, nbmax, sb1);
+        }
+        if (sb1 < nbmax) {
+            const int nt = (BIGB * (nbmax - sb1) + BGT - 1) / BGT;
+            hipLaunchKernelGGL(k_big_gemm, dim3(nt * (sb1 / 2 + 1), ut.n_ids), blk, 0, s, ut, p, 1, sb0, sb1, nt, 0.0);
+        }
     }
-    hipLaunchKernelGGL(k_big_zz, dim3(ut.n_ids), blk, 0, s, ut, p);
+    const int tbs = (ut.max_T + 3) / 4;
+    hipLaunchKernelGGL(k_big_zz, dim3(BIG_ZZ_PARTS, ut.n_ids), blk, 0, s, ut, p, tbs);
+    hipLaunchKernelGGL(k_big_zz_fold, dim3(ut.n_ids), dim3(64), 0, s, ut, p, tbs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4296,6 +4583,13 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
         }
     } else {
         hipLaunchKernelGGL((k_mgrad<1, 1, false, 0>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+    }
+    if (ut.max_T > SMALL_MAX_T) {
+        // units of more than 1024 points: M by the LDS-staged GEMM into their K regions, then the reductions alone
+        const int nt = (16 * ut.max_T + BGT - 1) / BGT;
+        hipLaunchKernelGGL(k_big_gemm, dim3(nt * (nt + 1) / 2, ut.n_ids), dim3(256), 0, s, ut, p, 2, 0, 0, nt, (double)kp.dy);
+        if (dist_id == 0 && kern_id == 0) hipLaunchKernelGGL((k_mgrad<0, 0, false, 0, true>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
+        else hipLaunchKernelGGL((k_mgrad<1, 1, false, 0, true>), grid, dim3(256), 0, s, utp, p, kp, want_gc, pm);
     }
 #endif
 }
