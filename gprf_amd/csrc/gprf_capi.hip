@@ -912,7 +912,12 @@ int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *re
         c->poll_pending = false;
     } else if (c->io_mode == 1 && !c->poisoned && !potrf_tool_env()) {
         // the copy-based form's own completion: the runtime's stream synchronisation
-        HIP_TRY(c, hipStreamSynchronize(s));
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            c->eval_pending = false;
+            c->poll_pending = false;
+            return fail(c, GPRF_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        }
     } else {
         int rc = bounded_stream_wait(c, s);
         if (rc != GPRF_OK) { c->eval_pending = false; return rc; }

@@ -284,23 +284,31 @@ struct Hav {
 // instead of ~100 / ~190 instructions.  Farther pairs take the closed form (a wave-uniform branch skips it when no lane
 // needs it).
 constexpr double HAV_A0 = 0.04;
+// Round 5: a <= 1.5e-3 (great-circle distance <= 490 km: every pair of a block or of neighbouring blocks at the seismic
+// configuration's block size) needs the first SIX terms only — the seventh is 0.05 a^6 < 6e-19 of Q, 0.34 a^6 < 4e-18 of D — half
+// the multiply-adds of the gradient kernel's two polynomials.  The degree is chosen per pair by its own a, so a pair's value
+// is the same wherever it is evaluated (fill, gradient, neighbour discovery).
+constexpr double HAV_A1 = 1.5e-3;
+template <int DEG>
 __device__ static __forceinline__ double hav_poly(double a, const double (&c)[12]) {
-    double r = c[11];
+    double r = c[DEG];
 #pragma unroll
-    for (int n = 10; n >= 0; --n) r = __builtin_fma(r, a, c[n]);
+    for (int n = DEG - 1; n >= 0; --n) r = __builtin_fma(r, a, c[n]);
     return r;
 }
+template <int DEG>
 __device__ static __forceinline__ double hav_Q(double a) {
     const double c[12] = {0x1.0000000000000p+0, 0x1.5555555555555p-2, 0x1.6c16c16c16c17p-3, 0x1.d41d41d41d41dp-4,
                           0x1.4ce19ae67b348p-4, 0x1.f85d955d36cbbp-5, 0x1.8f0ef795b5337p-5, 0x1.45e5d2ba42ea0p-5,
                           0x1.10a57fc5a815cp-5, 0x1.d0ef1a8f09124p-6, 0x1.928a4e67e4640p-6, 0x1.60f3b40d2e48ep-6};
-    return hav_poly(a, c);
+    return hav_poly<DEG>(a, c);
 }
+template <int DEG>
 __device__ static __forceinline__ double hav_D(double a) {
     const double c[12] = {0x1.0000000000000p+0, 0x1.5555555555555p-1, 0x1.1111111111111p-1, 0x1.d41d41d41d41dp-2,
                           0x1.a01a01a01a01ap-2, 0x1.7a463005e918cp-2, 0x1.5d2d18a2fe8d0p-2, 0x1.45e5d2ba42ea0p-2,
                           0x1.32ba2fbe5d188p-2, 0x1.2295709965ab6p-2, 0x1.14bf15e76d04cp-2, 0x1.08b6c709e2b6ap-2};
-    return hav_poly(a, c);
+    return hav_poly<DEG>(a, c);
 }
 template <bool GRAD>
 __device__ static __forceinline__ Hav haversine(const double *gi, const double *gj) {
@@ -319,9 +327,12 @@ __device__ static __forceinline__ Hav haversine(const double *gi, const double *
     if (a > 1.0) a = 1.0;
     h.a = a;
     h.ggp = 0.0;
-    if (__builtin_expect(a <= HAV_A0, 1)) {
-        h.g2 = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a * hav_Q(a));
-        if constexpr (GRAD) h.ggp = (2.0 * EARTH_R_KM * EARTH_R_KM) * hav_D(a);
+    if (__builtin_expect(a <= HAV_A1, 1)) {
+        h.g2 = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a * hav_Q<5>(a));
+        if constexpr (GRAD) h.ggp = (2.0 * EARTH_R_KM * EARTH_R_KM) * hav_D<5>(a);
+    } else if (a <= HAV_A0) {
+        h.g2 = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a * hav_Q<11>(a));
+        if constexpr (GRAD) h.ggp = (2.0 * EARTH_R_KM * EARTH_R_KM) * hav_D<11>(a);
     } else {
         double g = 2.0 * asin(sqrt(a)) * EARTH_R_KM;
         h.g2 = g * g;
@@ -331,13 +342,31 @@ __device__ static __forceinline__ Hav haversine(const double *gi, const double *
     return h;
 }
 
+// sqrt of x >= 0 from the hardware reciprocal-square-root seed, two Newton steps and a residual correction (the pivot chain's
+// sqrt_and_rsqrt without the reciprocal): 9 instructions against the library sqrt's ~20 with its range scaling — x is a
+// squared scaled distance here, 0 or O(1e-12 .. 1e4); 0 stays 0 (the seed of 0 is inf: guarded)
+__device__ static __forceinline__ double sqrt_nn(double x) {
+    double xs = x > 1e-280 ? x : 1e-280;
+    double y = __builtin_amdgcn_rsq(xs);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        double t = xs * y;
+        double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    double d = xs * y;
+    double r = fma(-d, d, xs);
+    d = fma(r, 0.5 * y, d);
+    return x > 1e-280 ? d : 0.0;
+}
+
 template <>
 struct KernFn<1, 1> {
     __device__ static __forceinline__ double value(const KParams &p, const double *gi, const double *gj) {
         Hav h = haversine<false>(gi, gj);
         double il0 = p.inv_ls[0];
         double dd = (gi[GEO_Z] - gj[GEO_Z]) * p.inv_ls[1];
-        double r = sqrt(h.g2 * (il0 * il0) + dd * dd);
+        double r = sqrt_nn(h.g2 * (il0 * il0) + dd * dd);
         double s3r = SQRT3 * r;
         return p.sv * (1.0 + s3r) * exp_fast(-s3r);
     }
@@ -351,7 +380,7 @@ struct KernFn<1, 1> {
         double il02 = il0 * il0, il12 = il1 * il1;
         double dz = gj[GEO_Z] - gi[GEO_Z];
         double dd = dz * il1;
-        double r = sqrt(h.g2 * il02 + dd * dd);
+        double r = sqrt_nn(h.g2 * il02 + dd * dd);
         double s3r = SQRT3 * r;
         double e = exp_fast(-s3r);
         double k = p.sv * (1.0 + s3r) * e;
@@ -370,6 +399,111 @@ struct KernFn<1, 1> {
         dkdl[0] = -c * h.g2 * (il02 * il0);
         dkdl[1] = -c * dz * dz * (il12 * il1);
         return k;
+    }
+    // pair() for the FOUR row points of a lane against one column point, written step-major (round 5).  One pair evaluation is
+    // a dependent chain ~60 operations long (haversine -> two Horner polynomials -> rsq Newton -> exp Horner) and a dependent
+    // fp64 operation has ~16 cycles of latency: entry by entry the gradient kernel's reductions took 39.6 k cycles of a block
+    // pair against 15.7 k for its MFMA chunks (round 4 stamps) — latency, not instruction count (halving the polynomials and
+    // the sqrt changed nothing).  Here the four chains advance together, every step over q before the next step, and what
+    // depends on the column point alone is formed once.  The fast path (every lane's four pairs within 490 km: the same
+    // degree-5 polynomials the scalar code picks for each of them) is the same arithmetic per pair; anything else falls back
+    // to pair() entry by entry.
+    __device__ static __forceinline__ void pair4(const KParams &p, const double (&gi)[4][GEO_N], const double *gj, double (&kk)[4],
+                                                 double (&dxi)[4][3], double (&dxj)[4][3], double (&dl)[4][3]) {
+        double s1[4], s2[4], cli[4], a[4];
+        const double clj = gj[GEO_CLH] * gj[GEO_CLH] - gj[GEO_SLH] * gj[GEO_SLH];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s1[q] = gj[GEO_SLH] * gi[q][GEO_CLH] - gj[GEO_CLH] * gi[q][GEO_SLH];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s2[q] = gj[GEO_SNH] * gi[q][GEO_CNH] - gj[GEO_CNH] * gi[q][GEO_SNH];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cli[q] = gi[q][GEO_CLH] * gi[q][GEO_CLH] - gi[q][GEO_SLH] * gi[q][GEO_SLH];
+        bool near = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = s1[q] * s1[q] + cli[q] * clj * s2[q] * s2[q];
+            near = near && a[q] <= HAV_A1;
+        }
+        if (!__all(near)) {      // (wave-uniform) somebody's pair is farther than 490 km: the scalar code, degree by pair
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dxi[q][0] = dxi[q][1] = dxi[q][2] = dxj[q][0] = dxj[q][1] = dxj[q][2] = dl[q][0] = dl[q][1] = dl[q][2] = 0.0;
+                kk[q] = pair(p, gi[q], gj, false, 0.0, dxi[q], dxj[q], dl[q]);
+            }
+            return;
+        }
+        // asin(sqrt a)^2 = a Q(a),  asin(sqrt a) / sqrt(a (1 - a)) = D(a): the first six terms of hav_Q / hav_D, eight chains
+        const double cq[6] = {0x1.0000000000000p+0, 0x1.5555555555555p-2, 0x1.6c16c16c16c17p-3, 0x1.d41d41d41d41dp-4,
+                              0x1.4ce19ae67b348p-4, 0x1.f85d955d36cbbp-5};
+        const double cd[6] = {0x1.0000000000000p+0, 0x1.5555555555555p-1, 0x1.1111111111111p-1, 0x1.d41d41d41d41dp-2,
+                              0x1.a01a01a01a01ap-2, 0x1.7a463005e918cp-2};
+        double pq[4], pd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pq[q] = cq[5]; pd[q] = cd[5]; }
+#pragma unroll
+        for (int n = 4; n >= 0; --n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pq[q] = __builtin_fma(pq[q], a[q], cq[n]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pd[q] = __builtin_fma(pd[q], a[q], cd[n]);
+        }
+        const double il0 = p.inv_ls[0], il1 = p.inv_ls[1];
+        const double il02 = il0 * il0, il12 = il1 * il1;
+        double g2[4], ggp[4], dz[4], x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            g2[q] = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a[q] * pq[q]);
+            ggp[q] = (2.0 * EARTH_R_KM * EARTH_R_KM) * pd[q];
+            dz[q] = gj[GEO_Z] - gi[q][GEO_Z];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double dd = dz[q] * il1;
+            x[q] = g2[q] * il02 + dd * dd;
+            x[q] = x[q] > 1e-280 ? x[q] : 1e-280;      // (sqrt_nn, four chains: r = 0 comes out as 1e-140)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            double t[4], e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = x[q] * y[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = fma(-t[q], y[q], 1.0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = fma(0.5 * y[q], e[q], y[q]);
+        }
+        double r[4], ms3r[4], ex[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = x[q] * y[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = fma(fma(-r[q], r[q], x[q]), 0.5 * y[q], r[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ms3r[q] = -SQRT3 * r[q];
+        exp_fast_v<4>(ms3r, ex);
+        const double c1_0 = gj[GEO_CLH], s1_0 = gj[GEO_SLH], slj = 2.0 * gj[GEO_SLH] * gj[GEO_CLH];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            kk[q] = p.sv * (1.0 - ms3r[q]) * ex[q];
+            const double c = -3.0 * p.sv * ex[q];      // dk/dr = c r; r cancels against dr/d(.) = (.)/r
+            const double w = c * ggp[q] * (DEG2RAD * il02);
+            const double c1 = c1_0 * gi[q][GEO_CLH] + s1_0 * gi[q][GEO_SLH];
+            const double c2 = gj[GEO_CNH] * gi[q][GEO_CNH] + gj[GEO_SNH] * gi[q][GEO_SNH];
+            const double sli = 2.0 * gi[q][GEO_SLH] * gi[q][GEO_CLH];
+            const double s22 = s2[q] * s2[q], s1c1 = s1[q] * c1;
+            const double da_dlon = cli[q] * clj * s2[q] * c2;
+            dxj[q][0] = w * da_dlon;
+            dxi[q][0] = -w * da_dlon;
+            dxj[q][1] = w * (s1c1 - slj * cli[q] * s22);
+            dxi[q][1] = w * (-s1c1 - sli * clj * s22);
+            const double tz = c * dz[q] * il12;
+            dxj[q][2] = tz;
+            dxi[q][2] = -tz;
+            dl[q][0] = -c * g2[q] * (il02 * il0);
+            dl[q][1] = -c * dz[q] * dz[q] * (il12 * il1);
+            dl[q][2] = 0.0;
+        }
     }
 };
 
@@ -2651,6 +2785,10 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
         double xj[XN];
 #pragma unroll
         for (int d = 0; d < XN; ++d) xj[d] = xsh[(16 * wrow + lr) * XN + d];      // diagonal block: J block = I block
+        // (lld / Matern: the lane's four pair evaluations side by side, KernFn<1,1>::pair4)
+        double l_k[4], l_dxi[4][3], l_dxj[4][3], l_dl[4][3];
+        if constexpr (!(DIST == 0 && KERN == 0)) KernFn<DIST, KERN>::pair4(kp, xi, xj, l_k, l_dxi, l_dxj, l_dl);
+        (void)l_k; (void)l_dxi; (void)l_dxj; (void)l_dl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = 16 * I + lg + 4 * q;
@@ -2670,19 +2808,14 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
                     if constexpr (GC) gc_l[d] += gd * delta;
                 }
             } else {
-                {
-                    // (branch-free: padding entries have Mij = 0 and finite derivatives — the four entries of a lane are
-                    // independent chains the scheduler can interleave)
-                    double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
-                    double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
-                    const double Mo = (i != j) ? Mij : 0.0;
+                // (branch-free: padding entries have Mij = 0 and finite derivatives)
+                const double Mo = (i != j) ? Mij : 0.0;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) csd[d] += Mo * dkdxj[d];
-                    gc_tr += (i == j) ? Mij : 0.0;
-                    gc_sv += Mij * k;
+                for (int d = 0; d < 3; ++d) csd[d] += Mo * l_dxj[q][d];
+                gc_tr += (i == j) ? Mij : 0.0;
+                gc_sv += Mij * l_k[q];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
-                }
+                for (int d = 0; d < 3; ++d) gc_l[d] += Mij * l_dl[q][d];
             }
         }
     }
@@ -2714,6 +2847,9 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Kv[q] *= kp.sv;
             }
+            double l_k[4], l_dxi[4][3], l_dxj[4][3], l_dl[4][3];
+            if constexpr (!(DIST == 0 && KERN == 0)) KernFn<DIST, KERN>::pair4(kp, xi, xj, l_k, l_dxi, l_dxj, l_dl);
+            (void)l_k; (void)l_dxi; (void)l_dxj; (void)l_dl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int i = 16 * I + lg + 4 * q;
@@ -2731,18 +2867,14 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
                         if constexpr (GC) gc_l[d] += 2.0 * gd * delta;
                     }
                 } else {
-                    {
-                        double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
-                        double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            colsum[d] += Mij * dkdxj[d];
-                            rowsum[q][d] += Mij * dkdxi[d];
-                        }
-                        gc_sv += 2.0 * Mij * k;
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) gc_l[d] += 2.0 * Mij * dkdl[d];
+                    for (int d = 0; d < 3; ++d) {
+                        colsum[d] += Mij * l_dxj[q][d];
+                        rowsum[q][d] += Mij * l_dxi[q][d];
                     }
+                    gc_sv += 2.0 * Mij * l_k[q];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gc_l[d] += 2.0 * Mij * l_dl[q][d];
                 }
             }
         }
@@ -4564,7 +4696,9 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     // group (C4: 762 -> 738 us; launch-wide there the ten workgroups of a unit run far apart and each fetches the unit's W / At
     // from HBM again: 809).  diag part_major=0: unit by unit.
     const int pm = diag("part_major", 1) != 0 ? 1 : 0;
-    const int G = ut.n_ids > 2 * device_cus() ? 64 : 0;
+    // (round 5: the lld / Matern instantiation always in groups — its block pairs re-read W / At at 482 MB per launch walked
+    // launch-wide on the seismic shape — and never with fewer than two groups: part_major_map then walks launch-wide)
+    const int G = (ut.n_ids > 2 * device_cus() || (dist_id == 1 && ut.n_ids > 128)) ? 64 : 0;
     const int nbp = TBm * (TBm + 1) / 2;
     dim3 grid(pm && G > 0 ? ((ut.n_ids + G - 1) / G) * G * nbp : xcd_grid(ut.n_ids, nbp));
     UnitTab utp = ut;

@@ -16,13 +16,15 @@ def short(name):
     # the two instantiations that differ by where K comes from (demangled or mangled spelling)
     if "k_potrf_reg2" in name:
         return "k_potrf_reg2_gen"
-    if "k_potrf_reg8" in name:      # k_potrf_reg8<SLOTS, GEN, RA>: K generated, or read from the pool (lld / Matern, forced fills)
+    if "k_potrf_reg8w" in name:     # units of 21 .. 28 tiles, waiting tiles in the U pool
+        return "k_potrf_reg8w"
+    if "k_potrf_reg8" in name:      # k_potrf_reg8<SLOTS, GEN>: K generated, or read from the pool (lld / Matern, forced fills)
         return "k_potrf_reg8_pool" if ("<20, false" in name or "ILi20ELb0E" in name) else "k_potrf_reg8_gen"
-    if "k_potrf_reg" in name:
-        return "k_potrf_reg_gen" if (", true>" in name or "ELb1E" in name) else "k_potrf_reg"
+    if "k_mgrad" in name and (", true>" in name and "false, 0, true>" in name):
+        return "k_mgrad_big"
     if "k_mgrad" in name and ("<0, 0, true>" in name or "ILi0ELi0ELb1E" in name):
         return "k_mgrad_readK"
-    for k in ("k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at_wide", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
+    for k in ("k_big_gemm", "k_big_diag", "k_big_apply", "k_big_update", "k_big_zz_fold", "k_big_zz", "k_big_init", "k_fill", "k_potrf_reg", "k_potrf", "k_solve_panel", "k_solve", "k_at_wide", "k_at", "k_mgrad", "k_mtile", "k_gred", "k_gx_finalize", "k_assemble",
               "k_assign", "k_route", "k_build_scatter", "k_build", "k_scatter_x", "k_done", "k_finish", "k_pair_max"):
         if k in name:
             return k

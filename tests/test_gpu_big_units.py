@@ -1,7 +1,8 @@
 """Units of more than 1024 points (round 4): the reference has no size limit (gprf.py:496-591 is LAPACK on whatever the
 partition gives) and its experiment matrix uses such units — n = 10000 with 9 blocks (unaries of ~1100 points, pairs of
 ~2200) or ONE block, the full GP (gprfopt_analyze.py:237-238; BASELINE.md quotes their 6.64 / 85.3 / 233.5 s per
-evaluation).  Those units run through the blocked multi-launch path (k_big_*: 64 x 64 blocks).
+evaluation).  Those units run through the blocked multi-launch path (k_big_*: 64-row steps inside super-blocks of 256 rows,
+everything behind a super-block and the gradient matrix M by the LDS-staged MFMA GEMM k_big_gemm: DESIGN.md section 4.5).
 Checked: per unit against the oracle at m ~ 1100 and m ~ 2200 (ll, the factor's defining identities, gradX, gradC), a
 context that mixes every size class, and the reference's PUBLISHED objectives of the 9-block and 1-block runs."""
 import numpy as np
@@ -47,6 +48,33 @@ def test_units_of_1100_and_2200_points_against_the_oracle():
     assert np.max(np.abs(W @ U.T - np.eye(mp))) <= 1e-10
     s5 = ctx.debug_fetch(0, 5)
     assert abs(s5[1] - np.linalg.slogdet(K)[1]) <= 1e-10 * abs(s5[1])
+    g.close()
+
+
+def test_lld_matern_unit_of_1100_points_through_the_blocked_path():
+    """("lld","matern32") with a block of 1100 events and a pair of 1700: k_fill<lld, matern32>, the blocked Cholesky and
+    substitution, M by the LDS-staged GEMM and k_mgrad<lld, matern32, BIG>'s reductions — against the oracle's GPRFRef (the lld
+    arithmetic itself is parity-unpinned: what is checked is this path against the restatement, like every lld test)."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    from oracle.gprf_ref import GPRFRef
+    from oracle.vector_tree import GPCov as OC
+    rng = np.random.RandomState(12)
+    n, dy = 1700, 4
+    X = np.column_stack([rng.uniform(100.0, 106.0, n), rng.uniform(30.0, 34.0, n), rng.uniform(0.0, 60.0, n)])
+    Y = rng.randn(n, dy)
+    order = np.argsort(X[:, 0])
+    blocks = [np.sort(order[:1100]), np.sort(order[1100:])]
+    nbrs = [(1, 0)]
+    nv, sv, ls = 0.08, 1.4, [55.0, 30.0]
+    g = GPRF(X, Y, None, GPCov([sv], ls, "lld", "matern32"), nv, block_idxs=blocks, neighbors=nbrs)
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert g._ctx.max_T() > 64
+    o = GPRFRef(X, Y, None, OC([sv], ls, "lld", "matern32"), nv, block_idxs=blocks, neighbors=nbrs)
+    o_ll, o_gX, o_gC = o.llgrad(grad_X=True, grad_cov=True)
+    assert abs(ll - o_ll) <= 1e-11 * abs(o_ll)
+    assert np.max(np.abs(gX - o_gX)) <= 1e-9 * np.max(np.abs(o_gX))
+    assert np.allclose(gC, o_gC, rtol=1e-8)
     g.close()
 
 
