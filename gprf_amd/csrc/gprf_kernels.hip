@@ -400,111 +400,6 @@ struct KernFn<1, 1> {
         dkdl[1] = -c * dz * dz * (il12 * il1);
         return k;
     }
-    // pair() for the FOUR row points of a lane against one column point, written step-major (round 5).  One pair evaluation is
-    // a dependent chain ~60 operations long (haversine -> two Horner polynomials -> rsq Newton -> exp Horner) and a dependent
-    // fp64 operation has ~16 cycles of latency: entry by entry the gradient kernel's reductions took 39.6 k cycles of a block
-    // pair against 15.7 k for its MFMA chunks (round 4 stamps) — latency, not instruction count (halving the polynomials and
-    // the sqrt changed nothing).  Here the four chains advance together, every step over q before the next step, and what
-    // depends on the column point alone is formed once.  The fast path (every lane's four pairs within 490 km: the same
-    // degree-5 polynomials the scalar code picks for each of them) is the same arithmetic per pair; anything else falls back
-    // to pair() entry by entry.
-    __device__ static __forceinline__ void pair4(const KParams &p, const double (&gi)[4][GEO_N], const double *gj, double (&kk)[4],
-                                                 double (&dxi)[4][3], double (&dxj)[4][3], double (&dl)[4][3]) {
-        double s1[4], s2[4], cli[4], a[4];
-        const double clj = gj[GEO_CLH] * gj[GEO_CLH] - gj[GEO_SLH] * gj[GEO_SLH];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s1[q] = gj[GEO_SLH] * gi[q][GEO_CLH] - gj[GEO_CLH] * gi[q][GEO_SLH];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s2[q] = gj[GEO_SNH] * gi[q][GEO_CNH] - gj[GEO_CNH] * gi[q][GEO_SNH];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cli[q] = gi[q][GEO_CLH] * gi[q][GEO_CLH] - gi[q][GEO_SLH] * gi[q][GEO_SLH];
-        bool near = true;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a[q] = s1[q] * s1[q] + cli[q] * clj * s2[q] * s2[q];
-            near = near && a[q] <= HAV_A1;
-        }
-        if (!__all(near)) {      // (wave-uniform) somebody's pair is farther than 490 km: the scalar code, degree by pair
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dxi[q][0] = dxi[q][1] = dxi[q][2] = dxj[q][0] = dxj[q][1] = dxj[q][2] = dl[q][0] = dl[q][1] = dl[q][2] = 0.0;
-                kk[q] = pair(p, gi[q], gj, false, 0.0, dxi[q], dxj[q], dl[q]);
-            }
-            return;
-        }
-        // asin(sqrt a)^2 = a Q(a),  asin(sqrt a) / sqrt(a (1 - a)) = D(a): the first six terms of hav_Q / hav_D, eight chains
-        const double cq[6] = {0x1.0000000000000p+0, 0x1.5555555555555p-2, 0x1.6c16c16c16c17p-3, 0x1.d41d41d41d41dp-4,
-                              0x1.4ce19ae67b348p-4, 0x1.f85d955d36cbbp-5};
-        const double cd[6] = {0x1.0000000000000p+0, 0x1.5555555555555p-1, 0x1.1111111111111p-1, 0x1.d41d41d41d41dp-2,
-                              0x1.a01a01a01a01ap-2, 0x1.7a463005e918cp-2};
-        double pq[4], pd[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { pq[q] = cq[5]; pd[q] = cd[5]; }
-#pragma unroll
-        for (int n = 4; n >= 0; --n) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pq[q] = __builtin_fma(pq[q], a[q], cq[n]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pd[q] = __builtin_fma(pd[q], a[q], cd[n]);
-        }
-        const double il0 = p.inv_ls[0], il1 = p.inv_ls[1];
-        const double il02 = il0 * il0, il12 = il1 * il1;
-        double g2[4], ggp[4], dz[4], x[4], y[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            g2[q] = (4.0 * EARTH_R_KM * EARTH_R_KM) * (a[q] * pq[q]);
-            ggp[q] = (2.0 * EARTH_R_KM * EARTH_R_KM) * pd[q];
-            dz[q] = gj[GEO_Z] - gi[q][GEO_Z];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double dd = dz[q] * il1;
-            x[q] = g2[q] * il02 + dd * dd;
-            x[q] = x[q] > 1e-280 ? x[q] : 1e-280;      // (sqrt_nn, four chains: r = 0 comes out as 1e-140)
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            double t[4], e[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = x[q] * y[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = fma(-t[q], y[q], 1.0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) y[q] = fma(0.5 * y[q], e[q], y[q]);
-        }
-        double r[4], ms3r[4], ex[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = x[q] * y[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = fma(fma(-r[q], r[q], x[q]), 0.5 * y[q], r[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ms3r[q] = -SQRT3 * r[q];
-        exp_fast_v<4>(ms3r, ex);
-        const double c1_0 = gj[GEO_CLH], s1_0 = gj[GEO_SLH], slj = 2.0 * gj[GEO_SLH] * gj[GEO_CLH];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            kk[q] = p.sv * (1.0 - ms3r[q]) * ex[q];
-            const double c = -3.0 * p.sv * ex[q];      // dk/dr = c r; r cancels against dr/d(.) = (.)/r
-            const double w = c * ggp[q] * (DEG2RAD * il02);
-            const double c1 = c1_0 * gi[q][GEO_CLH] + s1_0 * gi[q][GEO_SLH];
-            const double c2 = gj[GEO_CNH] * gi[q][GEO_CNH] + gj[GEO_SNH] * gi[q][GEO_SNH];
-            const double sli = 2.0 * gi[q][GEO_SLH] * gi[q][GEO_CLH];
-            const double s22 = s2[q] * s2[q], s1c1 = s1[q] * c1;
-            const double da_dlon = cli[q] * clj * s2[q] * c2;
-            dxj[q][0] = w * da_dlon;
-            dxi[q][0] = -w * da_dlon;
-            dxj[q][1] = w * (s1c1 - slj * cli[q] * s22);
-            dxi[q][1] = w * (-s1c1 - sli * clj * s22);
-            const double tz = c * dz[q] * il12;
-            dxj[q][2] = tz;
-            dxi[q][2] = -tz;
-            dl[q][0] = -c * g2[q] * (il02 * il0);
-            dl[q][1] = -c * dz[q] * dz[q] * (il12 * il1);
-            dl[q][2] = 0.0;
-        }
-    }
 };
 
 // what a kernel instantiation keeps per point: row stride in the gathered pool and values held in registers
@@ -2785,10 +2680,6 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
         double xj[XN];
 #pragma unroll
         for (int d = 0; d < XN; ++d) xj[d] = xsh[(16 * wrow + lr) * XN + d];      // diagonal block: J block = I block
-        // (lld / Matern: the lane's four pair evaluations side by side, KernFn<1,1>::pair4)
-        double l_k[4], l_dxi[4][3], l_dxj[4][3], l_dl[4][3];
-        if constexpr (!(DIST == 0 && KERN == 0)) KernFn<DIST, KERN>::pair4(kp, xi, xj, l_k, l_dxi, l_dxj, l_dl);
-        (void)l_k; (void)l_dxi; (void)l_dxj; (void)l_dl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = 16 * I + lg + 4 * q;
@@ -2808,14 +2699,19 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
                     if constexpr (GC) gc_l[d] += gd * delta;
                 }
             } else {
-                // (branch-free: padding entries have Mij = 0 and finite derivatives)
-                const double Mo = (i != j) ? Mij : 0.0;
+                {
+                    // (branch-free: padding entries have Mij = 0 and finite derivatives — the four entries of a lane are
+                    // independent chains the scheduler can interleave)
+                    double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
+                    double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
+                    const double Mo = (i != j) ? Mij : 0.0;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) csd[d] += Mo * l_dxj[q][d];
-                gc_tr += (i == j) ? Mij : 0.0;
-                gc_sv += Mij * l_k[q];
+                    for (int d = 0; d < 3; ++d) csd[d] += Mo * dkdxj[d];
+                    gc_tr += (i == j) ? Mij : 0.0;
+                    gc_sv += Mij * k;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) gc_l[d] += Mij * l_dl[q][d];
+                    for (int d = 0; d < 3; ++d) gc_l[d] += Mij * dkdl[d];
+                }
             }
         }
     }
@@ -2847,9 +2743,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Kv[q] *= kp.sv;
             }
-            double l_k[4], l_dxi[4][3], l_dxj[4][3], l_dl[4][3];
-            if constexpr (!(DIST == 0 && KERN == 0)) KernFn<DIST, KERN>::pair4(kp, xi, xj, l_k, l_dxi, l_dxj, l_dl);
-            (void)l_k; (void)l_dxi; (void)l_dxj; (void)l_dl;
+
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int i = 16 * I + lg + 4 * q;
@@ -2867,14 +2761,21 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2)
                         if constexpr (GC) gc_l[d] += 2.0 * gd * delta;
                     }
                 } else {
+                    {
+                        // (round 5 also wrote the lane's four pair evaluations step-major, four dependent chains advancing
+                        // together, haversine to exp: 240 us against 223 on the seismic shape, 88 bytes of scratch — the
+                        // reductions are bound by instruction issue, not by the chains' latency.  Dropped.)
+                        double dkdxi[3] = {0, 0, 0}, dkdxj[3] = {0, 0, 0}, dkdl[3] = {0, 0, 0};
+                        double k = KernFn<DIST, KERN>::pair(kp, xi[q], xj, false, 0.0, dkdxi, dkdxj, dkdl);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        colsum[d] += Mij * l_dxj[q][d];
-                        rowsum[q][d] += Mij * l_dxi[q][d];
+                        for (int d = 0; d < 3; ++d) {
+                            colsum[d] += Mij * dkdxj[d];
+                            rowsum[q][d] += Mij * dkdxi[d];
+                        }
+                        gc_sv += 2.0 * Mij * k;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gc_l[d] += 2.0 * Mij * dkdl[d];
                     }
-                    gc_sv += 2.0 * Mij * l_k[q];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) gc_l[d] += 2.0 * Mij * l_dl[q][d];
                 }
             }
         }
@@ -3726,6 +3627,10 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
         }
 }
 
+// (Round 5 also ran the forward substitution BESIDE the Cholesky — super-block S of the substitution needs U's rows of S and
+// nothing behind them: a second queue, one event per super-block.  One block of 10000 points: 50.5 ms against 40.0 one after the
+// other — the Cholesky's small, latency-critical launches (k_big_diag needs 90 KB of LDS) then wait for a CU to drain behind
+// the other queue's GEMM workgroups.  Removed.)
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
@@ -3801,6 +3706,7 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 //   one_queue=1     both Cholesky instantiations on the main queue          side_events=1 fork / join of the two queues by events
 //   part_major=0/1  solve / gradient grids unit by unit / part by part      potrf_reg=0   every unit through the generic Cholesky
 //   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-28 tiles on the generic kernel
+//   pipe=<percent>  solve / At / gradient as two pipelines (off)            max_unit=<points>  a lower GPRF_MAX_UNIT (refusal-path tests)
 //   potrf_stamps=1..3  which wave's cycle stamps a -DGPRF_PROFILE build records
 // Read at every call (a handful of string searches per evaluation): a test may change it between two contexts of one process.
 int diag(const char *key, int dflt) {
