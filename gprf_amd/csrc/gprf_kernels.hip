@@ -3160,7 +3160,7 @@ __device__ __forceinline__ void big_block_mma(const double *__restrict__ SA, int
     }
 }
 
-// K's upper blocks -> U; W = identity on its diagonal blocks, zero on the blocks below; Z = Y[unit rows], zero padded.
+// K's upper blocks -> U; W = identity (all of it); Z = Y[unit rows], zero padded.
 // grid.x = nbmax * nbmax + nbmax: block (i, j) of the launch-wide block grid, then one workgroup per block row for Z.
 __global__ __launch_bounds__(256) void k_big_init(UnitTab ut, Pools pl, int nbmax, int dy) {
     BigUnit b;
@@ -3186,7 +3186,9 @@ __global__ __launch_bounds__(256) void k_big_init(UnitTab ut, Pools pl, int nbma
         int row = BIGB * i + (e >> 6), col = BIGB * j + (e & 63);
         if (row < b.mp && col < b.mp) {
             if (j >= i) U[row * mp + col] = K[row * mp + col];
-            if (j <= i) W[row * mp + col] = (row == col) ? 1.0 : 0.0;
+            // (W = I on EVERY block, the strictly-upper ones too: k_big_gemm walks W in 128-wide tiles that straddle the
+            // diagonal, and what is above it must be zero, not what an earlier partition left in the pool)
+            W[row * mp + col] = (row == col) ? 1.0 : 0.0;
         }
     }
 }

@@ -78,6 +78,36 @@ def test_lld_matern_unit_of_1100_points_through_the_blocked_path():
     g.close()
 
 
+def test_blocked_path_ignores_what_an_earlier_partition_left_in_the_pools():
+    """The pools are reused from evaluation to evaluation and from partition to partition.  k_big_gemm walks W in 128-wide
+    tiles that straddle the diagonal: what lies above the diagonal must be zero by construction, not by the luck of fresh
+    memory (round 5: it was not — found by the whole-trace test, whose pairs wander across the 1024-point limit).  A context
+    first evaluates two blocks of 760 / 740 points and their pair (1500 points: every pool fully written), then is given ONE
+    block of 1400 of the same points in another order: bit for bit the result of a fresh context."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(19)
+    n, dy = 1500, 5
+    X = rng.rand(n, 2) * [1.5, 1.0]
+    Y = rng.randn(n, dy)
+    order = np.argsort(X[:, 0])
+    cov = GPCov([1.1], [0.14, 0.16], "euclidean", "se")
+    g = GPRF(X, Y, None, cov, 0.03, block_idxs=[np.sort(order[:760]), np.sort(order[760:])], neighbors=[(1, 0)])
+    first = g.llgrad(grad_X=True, grad_cov=True)
+    assert np.isfinite(first[0])
+    one = [np.sort(rng.permutation(n)[:1400])]
+    g.block_idxs = one + [np.zeros(0, dtype=np.int64)]          # (the block count is fixed at construction: the second block empties)
+    g.neighbors = []
+    g.compute_neighbor_count()
+    again = g.llgrad(grad_X=True, grad_cov=True)
+    fresh_g = GPRF(X, Y, None, cov, 0.03, block_idxs=one + [np.zeros(0, dtype=np.int64)], neighbors=[])
+    fresh = fresh_g.llgrad(grad_X=True, grad_cov=True)
+    assert again[0] == fresh[0] and np.array_equal(again[1], fresh[1]) and np.array_equal(again[2], fresh[2])
+    o_ll, o_gX, o_gC = _oracle(X, Y, one, [], 0.03, 1.1, [0.14, 0.16]).llgrad(grad_X=True, grad_cov=True)
+    assert abs(again[0] - o_ll) <= 1e-11 * abs(o_ll) and np.max(np.abs(again[1] - o_gX)) <= 1e-9 * np.max(np.abs(o_gX))
+    g.close(); fresh_g.close()
+
+
 def test_every_size_class_in_one_context():
     """blocks of 1200 / 300 / 200 points with pairs (1, 0) and (2, 1): units of 1200 and 1500 points (blocked path), 500 (the
     generic one-workgroup Cholesky), 300 and 200 (register-resident) side by side; then a re-partitioning walk"""
