@@ -173,8 +173,12 @@ struct ObjTab {
 
 // re-blocking: nearest centre / split-tree descent of every point, with the per-chunk ranks and counts the table
 // build starts from (bt.assign / rank / cnt; ctl[CTL_CHANGED] = epoch when somebody moved)
-void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const BuildTab &bt,
-                   int epoch, hipStream_t s);
+// GridHint: the centres are a separable, uniformly spaced g x g grid (centre ix * g + iy = (a0 + ix ha, b0 + iy hb) to 1e-9 of
+// the spacing; dx = 2): k_assign then evaluates the reference's radicand on the 3 x 3 centres around a point's cell only —
+// the same values in the same order as the full scan, whose other centres are farther by at least 1.75 h^2 (g = 0: no grid)
+struct GridHint { int g; double a0, inv_ha, b0, inv_hb; };
+void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const GridHint &gh,
+                   const BuildTab &bt, int epoch, hipStream_t s);
 void launch_route(const double *X, double *Xcopy, int dx, int dim, int lon_wrap, const double *vec, const double *center,
                   const double *split, const int32_t *left, const int32_t *right, const int32_t *leaf_block,
                   const BuildTab &bt, int epoch, hipStream_t s);

@@ -88,6 +88,7 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("one Cholesky queue", {"GPRF_DIAG": "one_queue=1"}),
                       ("fork / join of the two Cholesky queues by events", {"GPRF_DIAG": "side_events=1"}),
                       ("solve / gradient grids walked unit by unit", {"GPRF_DIAG": "part_major=0"}),
+                      ("nearest centre by the full scan instead of the grid's 3 x 3", {"GPRF_DIAG": "grid_hint=0"}),
                       ("all of these at once", {"GPRF_DIAG": "fused_build=0,gx_fold=0,one_queue=1,part_major=0"})):
         assert run_variant(tmp_path, env) == base, name
 
