@@ -3415,15 +3415,19 @@ __global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb
     d4 acc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = d4{0.0, 0.0, 0.0, 0.0};
+    // (the 16 values of C requested together, in front of the block product's own loads: element by element, "*cp = *cp - acc"
+    // is load, wait, store sixteen times over)
+    double cv[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cv[jt][q] = C[(size_t)(16 * wave + lg + 4 * q) * ldc + (jt < nj ? 16 * jt + lr : lr)];
     big_block_mma(Uk + (size_t)BIGB * i + 16 * wave, b.mp, SB, ldc, kn, nj, lane, acc);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
         if (jt < nj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double *cp = C + (size_t)(16 * wave + lg + 4 * q) * ldc + 16 * jt + lr;
-                *cp = *cp - acc[jt][q];
-            }
+            for (int q = 0; q < 4; ++q) C[(size_t)(16 * wave + lg + 4 * q) * ldc + 16 * jt + lr] = cv[jt][q] - acc[jt][q];
 }
 
 // ||Z[:, 16 cb : 16 cb + 16]||_F^2 per column block (the small kernels' zzpart), fixed order: BIG_ZZ_PARTS workgroups per unit sum
@@ -3498,14 +3502,18 @@ __device__ __forceinline__ void bg_accumulate(const BgOp &op, int a_ext, int b_e
     const bool isB = wave >= 2;
     const int col = 64 * (wave & 1) + lane;
     const bool col_ok = col < (isB ? b_ext : a_ext);
-    const double *src0 = (isB ? op.B : op.A) + col;
+    // (branch-free: a lane beyond the operand's edge re-reads column 0 — its values only reach accumulator rows / columns
+    // that are never stored — and K is a multiple of BG_KC on every path (multiples of 16).  Written with a select per value,
+    // "col_ok && row < K ? load : 0", the compiler fenced every pair of loads with exec branches and s_waitcnt vmcnt(0):
+    // four serialised round trips per chunk, the loop ran on the latency of its own prefetch)
+    const double *src0 = (isB ? op.B : op.A) + (col_ok ? col : 0);
     const int ld = isB ? op.ldb : op.lda;
-    const int nch = (op.K + BG_KC - 1) / BG_KC;
+    const int nch = op.K / BG_KC;
     double pre0[BG_KC], pre1[BG_KC];
     auto fetch = [&](int c, double (&pre)[BG_KC]) {
         const double *src = src0 + (size_t)(BG_KC * c) * ld;
 #pragma unroll
-        for (int e = 0; e < BG_KC; ++e) pre[e] = (col_ok && BG_KC * c + e < op.K) ? src[(size_t)e * ld] : 0.0;
+        for (int e = 0; e < BG_KC; ++e) pre[e] = src[(size_t)e * ld];
     };
     auto step = [&](int c, double (&pre)[BG_KC]) {
         double *buf = sm + (c & 1) * (2 * BG_KC * BG_LD);
@@ -3611,22 +3619,34 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
     }
     if (skip) return;
     const int rbase = 64 * (wave >> 1), cbase = 64 * (wave & 1);
+    // C -= acc, one row of four tiles at a time: its 16 loads all in flight, then 16 stores (an element-wise "*cp = *cp - acc"
+    // compiles to load, s_waitcnt vmcnt(0), store, 64 times over: 64 exposed memory round trips per lane and tile); lanes
+    // beyond the tile's edge read the tile's first element and store nothing
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
+    for (int ii = 0; ii < 4; ++ii) {
+        double cv[4][4];
+        if (mode != 2) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int cc = cbase + 16 * jj + lr;
-            if (cc < b_ext) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const int cc = cbase + 16 * jj + lr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int rr = rbase + 16 * ii + lg + 4 * q;
-                    if (rr < a_ext) {
-                        double *cp = C + (size_t)rr * ldc + cc;
-                        *cp = mode == 2 ? acc[ii][jj][q] : *cp - acc[ii][jj][q];
-                    }
+                    const bool ok = cc < b_ext && rr < a_ext;
+                    cv[jj][q] = C[ok ? (size_t)rr * ldc + cc : (size_t)0];
                 }
             }
         }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int cc = cbase + 16 * jj + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = rbase + 16 * ii + lg + 4 * q;
+                if (cc < b_ext && rr < a_ext) C[(size_t)rr * ldc + cc] = mode == 2 ? acc[ii][jj][q] : cv[jj][q] - acc[ii][jj][q];
+            }
+        }
+    }
 }
 
 // (Round 5 also ran the forward substitution BESIDE the Cholesky — super-block S of the substitution needs U's rows of S and
