@@ -289,11 +289,19 @@ constexpr double HAV_A0 = 0.04;
 // the multiply-adds of the gradient kernel's two polynomials.  The degree is chosen per pair by its own a, so a pair's value
 // is the same wherever it is evaluated (fill, gradient, neighbour discovery).
 constexpr double HAV_A1 = 1.5e-3;
+// (the coefficient of a Horner step as a SCALAR operand of v_fma_f64, like exp_fast's: left to the compiler every step is a
+// v_fmac_f64 whose addend — the coefficient — is first moved into the destination register pair, two v_mov_b32 per step, a
+// fifth of the vector instructions of a pair evaluation in k_mgrad<1,1>; the same arithmetic, the same bits)
+__device__ __forceinline__ double fma_sc_free(double a, double b, double c_scalar) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+    return d;
+}
 template <int DEG>
 __device__ static __forceinline__ double hav_poly(double a, const double (&c)[12]) {
     double r = c[DEG];
 #pragma unroll
-    for (int n = DEG - 1; n >= 0; --n) r = __builtin_fma(r, a, c[n]);
+    for (int n = DEG - 1; n >= 0; --n) r = fma_sc_free(r, a, c[n]);
     return r;
 }
 template <int DEG>
@@ -2460,7 +2468,10 @@ __device__ __forceinline__ double row16_sum(double v) {
 // four times this kernel's flops per byte) and wait in the unit's region of the K pool: the chunk loop is skipped, the
 // accumulators are loaded, the reductions are the same code.  The plain instantiations leave those units alone.
 template <int DIST, int KERN, bool HAVEK, int FAST, bool BIG = false>
-__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : 2) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
+#ifndef GPRF_MGRAD_LLD_WPC
+#define GPRF_MGRAD_LLD_WPC 2
+#endif
+__global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : GPRF_MGRAD_LLD_WPC) void k_mgrad(UnitTab ut, Pools pl, KParams kp, int want_gc, int part_major) {
     static_assert(!(BIG && HAVEK), "the big units' K region holds M: their kernel values are re-evaluated");
     __shared__ double chunk[2][16 * G2_LD];
     // the coordinates (or lld records) of the I block's and the J block's points, fetched at kernel start so that the
@@ -2942,35 +2953,65 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
         __shared__ int s_notpd;
         if (threadIdx.x == 0) s_notpd = 0;
         __syncthreads();
-        for (int u = threadIdx.x; u < ut.n_units; u += 256) {
-            if (pl.info[u] != 0) atomicAdd(&s_notpd, 1);
-            if (usum_ok) {                        // the terms k_gx_finalize left (same values, same order of addition)
-                const double *us = pl.usum + (size_t)u * 8;
-                acc[0] += us[0];
-                if (want_gc)
-                    for (int t = 1; t < 6; ++t) acc[t] += us[t];
-                continue;
+        // Four units per thread and pass, every unit's words requested before the first is used (a thread beyond the last unit
+        // re-reads unit 0 and adds nothing): unit by unit — status word, size, then the sums — each unit was two or three
+        // dependent memory round trips, and this workgroup is the tail of the evaluation.  Same terms, same order of addition.
+        constexpr int NB = 4;
+        for (int u0 = threadIdx.x; u0 < ut.n_units; u0 += 256 * NB) {
+            int inf[NB], mm[NB];
+            double ww[NB], ld[NB], zq[NB][4], us[NB][6];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int u = u0 + 256 * j, uc = u < ut.n_units ? u : 0;
+                inf[j] = pl.info[uc];
+                if (usum_ok) {
+                    const double *up = pl.usum + (size_t)uc * 8;
+                    us[j][0] = up[0];
+                    if (want_gc)
+#pragma unroll
+                        for (int t = 1; t < 6; ++t) us[j][t] = up[t];
+                } else {
+                    mm[j] = ut.m[uc];
+                    ww[j] = ut.weight[uc];
+                    ld[j] = pl.logdet[uc];
+                    const double *zp = pl.zzpart + (size_t)uc * 4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) zq[j][t] = zp[t];
+                }
             }
-            int m = ut.m[u];
-            double w = ut.weight[u];
-            if (m > 0) {
-                const double *zp = pl.zzpart + (size_t)u * 4;
-                double zz = (zp[0] + zp[1]) + (zp[2] + zp[3]);
-                double ll = -0.5 * zz - 0.5 * kp.dy * pl.logdet[u] -
-                            0.5 * kp.dy * m * 1.8378770664093454836 /* log 2pi */;
-                acc[0] += w * ll;
-                if (want_gc) {
-                    int T = pad16(m) >> 4;
-                    int TB = (T + 3) >> 2, TBm = (ut.max_T + 3) >> 2;
-                    int nP = TB * (TB + 1) / 2;   // k_mgrad writes one partial per 64x64 block pair
-                    double g[5] = {0, 0, 0, 0, 0};
-                    for (int P = 0; P < nP; ++P) {
-                        const double *gp = pl.gcpart + ((size_t)u * (TBm * (TBm + 1) / 2) + P) * GC_SLOTS;
-                        for (int t = 0; t < 5; ++t) g[t] += gp[t];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int u = u0 + 256 * j;
+                if (u >= ut.n_units) continue;
+                if (inf[j] != 0) atomicAdd(&s_notpd, 1);
+                if (usum_ok) {                        // the terms k_gx_finalize left (same values, same order of addition)
+                    acc[0] += us[j][0];
+                    if (want_gc)
+#pragma unroll
+                        for (int t = 1; t < 6; ++t) acc[t] += us[j][t];
+                    continue;
+                }
+                const int m = mm[j];
+                const double w = ww[j];
+                if (m > 0) {
+                    double zz = (zq[j][0] + zq[j][1]) + (zq[j][2] + zq[j][3]);
+                    double ll = -0.5 * zz - 0.5 * kp.dy * ld[j] -
+                                0.5 * kp.dy * m * 1.8378770664093454836 /* log 2pi */;
+                    acc[0] += w * ll;
+                    if (want_gc) {
+                        int T = pad16(m) >> 4;
+                        int TB = (T + 3) >> 2, TBm = (ut.max_T + 3) >> 2;
+                        int nP = TB * (TB + 1) / 2;   // k_mgrad writes one partial per 64x64 block pair
+                        double g[5] = {0, 0, 0, 0, 0};
+                        const double *gp0 = pl.gcpart + ((size_t)u * (TBm * (TBm + 1) / 2)) * GC_SLOTS;
+                        for (int P = 0; P < nP; ++P) {
+                            const double *gp = gp0 + (size_t)P * GC_SLOTS;
+                            for (int t = 0; t < 5; ++t) g[t] += gp[t];
+                        }
+                        acc[1] += w * 0.5 * g[0];             // d/d nv   : 1/2 tr(M)
+                        acc[2] += w * 0.5 * g[1] / kp.sv;     // d/d sv   : 1/2 sum M k / sv
+                        for (int t = 0; t < 3; ++t) acc[3 + t] += w * 0.5 * g[2 + t];
                     }
-                    acc[1] += w * 0.5 * g[0];             // d/d nv   : 1/2 tr(M)
-                    acc[2] += w * 0.5 * g[1] / kp.sv;     // d/d sv   : 1/2 sum M k / sv
-                    for (int t = 0; t < 3; ++t) acc[3 + t] += w * 0.5 * g[2 + t];
                 }
             }
         }
@@ -2991,8 +3032,16 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
             gc[ncov] = at.ctl[CTL_OVERFLOW] ? 1.0 : 0.0;
             gc[ncov + 1] = (double)s_notpd;
         }
-        if (at.mirror_dst)
-            for (int i = threadIdx.x; i < at.mirror_n; i += 256) at.mirror_dst[i] = at.mirror_src[i];
+        if (at.mirror_dst) {      // (eight words per thread in flight: element by element it is load, wait, store)
+            for (int i0 = threadIdx.x; i0 < at.mirror_n; i0 += 8 * 256) {
+                int32_t w8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w8[q] = at.mirror_src[i0 + 256 * q < at.mirror_n ? i0 + 256 * q : 0];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + 256 * q < at.mirror_n) at.mirror_dst[i0 + 256 * q] = w8[q];
+            }
+        }
         return;
     }
     // gradX: 32 points per workgroup, 8 lanes per point — one per unit that contains the point's block, eight at a time
@@ -3003,19 +3052,87 @@ __global__ __launch_bounds__(256) void k_assemble(UnitTab ut, Pools pl, Assemble
     __shared__ int s_maxcnt;
     int t = threadIdx.x, i = t >> 3, e = t & 7;
     int p = (blockIdx.x - 1) * 32 + i;
-    bool live = want_gx && p < n && !at.ctl[CTL_OVERFLOW];
-    int e0 = 0, cnt = 0, pos = 0;
-    if (live) {      // (first CSR entry of the point's block, number of entries): k_scatter_x left them with the partition
-        e0 = at.pe[2 * p];
-        cnt = at.pe[2 * p + 1];
-        pos = at.posb[p];
-    }
+    // (first CSR entry of the point's block, number of entries): k_scatter_x left them with the partition.  Asked for together
+    // with the overflow word, not behind it (a thread without a point re-reads point 0)
+    const bool inb = want_gx && p < n;
+    const int pc = inb ? p : 0;
+    const int over_w = at.ctl[CTL_OVERFLOW];
+    const int2 pe2 = reinterpret_cast<const int2 *>(at.pe)[pc];
+    const int pos_l = at.posb[pc];
+    const bool live = inb && !over_w;
+    const int e0 = live ? pe2.x : 0, cnt = live ? pe2.y : 0, pos = live ? pos_l : 0;
     if (t == 0) s_maxcnt = 0;
     __syncthreads();
     if (e == 0 && cnt > 0) atomicMax(&s_maxcnt, cnt);
     __syncthreads();
     int maxcnt = s_maxcnt;
     double v = 0.0;                           // lane e < dx of point i carries coordinate e
+    const int tbs_l = (ut.max_T + 3) >> 2;
+    // The common shape — units of at most 256 points (four 64-point blocks), a point in at most 16 units, the partials folded
+    // here — with every memory round trip of a point's terms taken ONCE: (1) row, weight and block info of both of the lane's
+    // entries, (2) all eight partials of both rows.  The loop below is the same arithmetic for any shape; compiled, it is a
+    // chain of dependent trips — entry, then its info, then one trip per 64-point block of the column sums, then one per block
+    // of the row sums, twice over for a point in nine units: up to fourteen L2 latencies, most of this kernel's 12 us.
+    // A term the loop does not add enters here as + 0.0, which changes no bit of a sum that started from + 0.0.
+    if (at.fold_gx && tbs_l <= 4 && maxcnt <= 16) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        int rowq[2], infoq[2];
+        double wq[2];
+        bool okq[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            okq[j] = 8 * j + e < cnt;
+            const int idx = okq[j] ? e0 + 8 * j + e : 0;
+            const int eb = at.ebase[idx];
+            rowq[j] = okq[j] ? eb + pos : 0;      // (an entry nobody wrote — an empty block, an overflowed build — must not form an address)
+            wq[j] = at.ewgt[idx];
+            infoq[j] = at.einfo[idx];
+        }
+        // (2) exactly the partials the sums below add — the blocks IB = B .. TB - 1 of the column sums, JB = 0 .. B of the row
+        // sums, of the entries this lane has — behind exec masks, consumed only when all of them are in flight
+        const d2v zero2 = {0.0, 0.0};
+        d2v cq[2][4][2], rq[2][4][2];
+        int Bq[2], TBq[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            TBq[j] = infoq[j] & 0x3ff; Bq[j] = ((infoq[j] >> 10) + pos) >> 6;
+            const d2v *cp = reinterpret_cast<const d2v *>(pl.colpart + (size_t)rowq[j] * tbs_l * XPAD);
+            const d2v *rp = reinterpret_cast<const d2v *>(pl.rowpart + (size_t)rowq[j] * tbs_l * XPAD);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                cq[j][b][0] = zero2; cq[j][b][1] = zero2; rq[j][b][0] = zero2; rq[j][b][1] = zero2;
+                if (okq[j] && b >= Bq[j] && b < TBq[j]) { cq[j][b][0] = cp[2 * b]; cq[j][b][1] = cp[2 * b + 1]; }
+                if (okq[j] && b <= Bq[j] && b < tbs_l) { rq[j][b][0] = rp[2 * b]; rq[j][b][1] = rp[2 * b + 1]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (8 * j < maxcnt) {      // (uniform)
+                const int TB = TBq[j], B = Bq[j];
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const bool in = b >= B && b < TB;
+                    v0 += in ? cq[j][b][0][0] : 0.0; v1 += in ? cq[j][b][0][1] : 0.0; v2 += in ? cq[j][b][1][0] : 0.0;
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const bool in = b <= B;
+                    v0 += in ? rq[j][b][0][0] : 0.0; v1 += in ? rq[j][b][0][1] : 0.0; v2 += in ? rq[j][b][1][0] : 0.0;
+                }
+                term[i][e][0] = okq[j] ? wq[j] * v0 : 0.0;
+                term[i][e][1] = okq[j] ? wq[j] * v1 : 0.0;
+                term[i][e][2] = okq[j] ? wq[j] * v2 : 0.0;
+                __syncthreads();
+                if (e < dx) {
+                    int kn = cnt - 8 * j < 8 ? cnt - 8 * j : 8;
+                    for (int k = 0; k < kn; ++k) v += term[i][k][e];
+                }
+                __syncthreads();
+            }
+        }
+        maxcnt = 0;      // (the loop below has nothing left to do)
+    }
     for (int k0 = 0; k0 < maxcnt; k0 += 8) {
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
         if (k0 + e < cnt) {
@@ -3753,13 +3870,21 @@ int diag(const char *key, int dflt) {
 // order, exactly `all_idxs[blocks == i]` (block_clustering.py:21-24).  A point that changes block stamps
 // ctl[CTL_CHANGED] with this evaluation's epoch (no reset needed between evaluations).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void partition_tail(int p, int n, int best, const BuildTab &bt, int epoch,
+// partition_head: the part of it that depends on nothing — the point's block of the last evaluation is asked for and the
+// workgroup's row of cnt is zeroed at the START of the kernel, under the latency of the coordinates' own load (they may come
+// from pinned host memory) instead of as two more exposed round trips behind the search.
+__device__ __forceinline__ int partition_head(int p, int n, const BuildTab &bt) {
+    int *row = bt.cnt + (size_t)blockIdx.x * bt.n_blocks;
+    const int old = p < n ? bt.assign[p] : -1;
+    for (int b = threadIdx.x; b < bt.n_blocks; b += CHUNK) row[b] = 0;
+    return old;
+}
+__device__ __forceinline__ void partition_tail(int p, int n, int best, int old, const BuildTab &bt, int epoch,
                                                int *keys /* LDS [CHUNK], 16-byte aligned */) {
     int t = threadIdx.x;
     int *row = bt.cnt + (size_t)blockIdx.x * bt.n_blocks;
-    for (int b = t; b < bt.n_blocks; b += CHUNK) row[b] = 0;
     keys[t] = p < n ? best : -1;
-    __syncthreads();
+    __syncthreads();      // (also: the row's zeroes of partition_head are in memory before anybody writes a count)
     if (p >= n) return;
     int before = 0, total = 0;
     const int4 *k4 = reinterpret_cast<const int4 *>(keys);
@@ -3773,7 +3898,7 @@ __device__ __forceinline__ void partition_tail(int p, int n, int best, const Bui
     }
     bt.rank[p] = before;
     if (before == total - 1) row[best] = total;
-    if (bt.assign[p] != best) {
+    if (old != best) {
         bt.assign[p] = best;
         bt.ctl[CTL_CHANGED] = epoch;        // benign race: every writer stores the same value
     }
@@ -3803,9 +3928,14 @@ __global__ __launch_bounds__(CHUNK) void k_assign(const double *__restrict__ X, 
     int n = bt.n;
     int p = blockIdx.x * CHUNK + threadIdx.x;
     double x[DX], x2 = 0.0;
+    // (branch-free: a thread beyond n re-reads point n - 1 and stores nothing)
+    const int pl = p < n ? p : n - 1;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) x[d] = X[(size_t)pl * DX + d];
+    const int old = partition_head(p, n, bt);
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
-        x[d] = p < n ? X[(size_t)p * DX + d] : 0.0;
+        x[d] = p < n ? x[d] : 0.0;
         x2 = __dadd_rn(x2, __dmul_rn(x[d], x[d]));
     }
     if (Xcopy && p < n) {
@@ -3824,22 +3954,36 @@ __global__ __launch_bounds__(CHUNK) void k_assign(const double *__restrict__ X, 
             iy = iy < 0 ? 0 : (iy > g - 1 ? g - 1 : iy);
             const int ix0 = ix > 0 ? ix - 1 : 0, ix1 = ix < g - 1 ? ix + 1 : g - 1;
             const int iy0 = iy > 0 ? iy - 1 : 0, iy1 = iy < g - 1 ? iy + 1 : g - 1;
+            // all 27 centre values requested at once (a cell beyond the border re-reads its clamped neighbour and is left out of
+            // the comparison): written "if (inside) { load; compare }" every one of the nine was a branch, three loads and an
+            // s_waitcnt vmcnt(0) — nine memory round trips one after the other in a kernel that is nothing but latency
+            double c0v[9], c1v[9], c2v[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int kx = ix0 + a < ix1 ? ix0 + a : ix1, ky = iy0 + b < iy1 ? iy0 + b : iy1;
+                    const int k = kx * g + ky;
+                    c0v[3 * a + b] = cs[k];
+                    c1v[3 * a + b] = cs[(size_t)nc + k];
+                    c2v[3 * a + b] = c2[k];
+                }
+            }
             bool first = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     const int kx = ix0 + a, ky = iy0 + b;
-                    if (kx <= ix1 && ky <= iy1) {
-                        const int k = kx * g + ky;
-                        double r = 0.0;
-                        r = __dadd_rn(r, __dmul_rn(x[0], cs[k]));
-                        r = __dadd_rn(r, __dmul_rn(x[1], cs[(size_t)nc + k]));
-                        const double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2[k]);
-                        if (first) { bestv = v; best = k; first = false; }
-                        if (v < 0.0 && neg_k < 0) neg_k = k;
-                        if (v < bestv) { best = k; bestv = v; }
-                    }
+                    const bool inside = kx <= ix1 && ky <= iy1;
+                    const int k = kx * g + ky;
+                    double r = 0.0;
+                    r = __dadd_rn(r, __dmul_rn(x[0], c0v[3 * a + b]));
+                    r = __dadd_rn(r, __dmul_rn(x[1], c1v[3 * a + b]));
+                    const double v = __dadd_rn(__dsub_rn(x2, __dmul_rn(2.0, r)), c2v[3 * a + b]);
+                    if (inside && first) { bestv = v; best = k; first = false; }
+                    if (inside && v < 0.0 && neg_k < 0) neg_k = k;
+                    if (inside && v < bestv) { best = k; bestv = v; }
                 }
             }
             grid_done = true;
@@ -3866,7 +4010,7 @@ __global__ __launch_bounds__(CHUNK) void k_assign(const double *__restrict__ X, 
         }
     }
     if (neg_k >= 0) best = neg_k;
-    partition_tail(p, n, best, bt, epoch, keys);
+    partition_tail(p, n, best, old, bt, epoch, keys);
 }
 
 // k_route: the seismic driver's re-blocking (pdtree_clustering.py:65-94 via gprf.py:171-172): every point descends
@@ -3883,31 +4027,43 @@ __global__ __launch_bounds__(CHUNK) void k_route(const double *__restrict__ X, d
     int n = bt.n;
     int p = blockIdx.x * CHUNK + threadIdx.x;
     int best = 0;
+    const int old = partition_head(p, n, bt);
     if (p < n) {
         double x[3] = {0.0, 0.0, 0.0};              // dx <= 3 (gprf_create); fixed-bound loops keep x[] in registers
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (d < dx) {
-                x[d] = X[(size_t)p * dx + d];
-                if (Xcopy) Xcopy[(size_t)p * dx + d] = x[d];
-            }
+        for (int d = 0; d < 3; ++d) x[d] = X[(size_t)p * dx + (d < dx ? d : 0)];      // (branch-free: three loads in flight)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < dx && Xcopy) Xcopy[(size_t)p * dx + d] = x[d];
+            x[d] = d < dx ? x[d] : 0.0;
+        }
         if (lon_wrap) {
             double r = fmod(__dadd_rn(x[0], 22.0), 360.0);          // numpy's %: the result takes the divisor's sign
             if (r != 0.0) { if (r < 0.0) r = __dadd_rn(r, 360.0); } else r = 0.0;
             x[0] = __dsub_rn(r, 22.0);
         }
+        // one memory round trip per tree level: everything about node k is requested together (every array has an entry for
+        // every node, leaves included) — "while (left[k] >= 0) { ... }" asked for left[k], waited, then for the rest
         int k = 0;
-        while (left[k] >= 0) {
-            double a = __dmul_rn(__dsub_rn(x[0], center[(size_t)k * dim]), vec[(size_t)k * dim]);
+        for (;;) {
+            const int lk = left[k], rk = right[k];
+            const double sp = split[k];
+            double c[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int dd = d < dim ? d : 0;
+                c[d] = center[(size_t)k * dim + dd]; v[d] = vec[(size_t)k * dim + dd];
+            }
+            if (lk < 0) break;
+            double a = __dmul_rn(__dsub_rn(x[0], c[0]), v[0]);
 #pragma unroll
             for (int d = 1; d < 3; ++d)
-                if (d < dim)
-                    a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], center[(size_t)k * dim + d]), vec[(size_t)k * dim + d]));
-            k = (a < split[k]) ? left[k] : right[k];
+                if (d < dim) a = __dadd_rn(a, __dmul_rn(__dsub_rn(x[d], c[d]), v[d]));
+            k = (a < sp) ? lk : rk;
         }
         best = leaf_block[k];
     }
-    partition_tail(p, n, best, bt, epoch, keys);
+    partition_tail(p, n, best, old, bt, epoch, keys);
 }
 
 void launch_assign(const double *X, double *Xcopy, int dx, const double *cs, const double *c2, int nc, const GridHint &gh,
