@@ -2282,7 +2282,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
 // the snake gives 34 each) and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
-__global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int first_round) {
+__global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int first_round, int skip_T) {
     int slot_, part_;
     WgTrace trace(ut, pl, 2);
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
@@ -2295,7 +2295,7 @@ __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int fi
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int I0 = 16 * part_;
-    if (I0 >= T) return;
+    if (I0 >= T || T > skip_T) return;      // (skip_T: the units launch_big_at takes)
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     size_t roff = ur.row_off;
@@ -2351,7 +2351,7 @@ __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int fi
 // step's operands are already in flight.
 constexpr int AT_TILES = 8;    // column tiles of At per workgroup (two per wave)
 
-__global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
+__global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl, int skip_T) {
     int slot_, part_;
     WgTrace trace(ut, pl, 2);
     if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES, &slot_, &part_)) return;
@@ -2359,7 +2359,7 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl) {
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int I0 = AT_TILES * part_;
-    if (I0 >= T) return;
+    if (I0 >= T || T > skip_T) return;      // (skip_T: the units launch_big_at takes)
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
     size_t roff = ur.row_off;
@@ -2481,6 +2481,15 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : GP
     int slot, bp;
     WgTrace trace(ut, pl, 3);
     // (part_major: every unit's block pair 0 first, then every unit's pair 1, ...: pairs are in order of descending length)
+    if constexpr (BIG) {
+        // a unit of more than 1024 points is thousands of block pairs: consecutive workgroups = consecutive pairs of ONE unit,
+        // dealt round-robin over the XCDs by the dispatcher (the maps below keep a unit on one XCD, for its L2: the single
+        // 10000-point unit's 12403 pairs then ran on 32 of the 256 CUs, 1.2 ms instead of 0.2)
+        const int nbp = TBm * (TBm + 1) / 2;
+        slot = (int)blockIdx.x / nbp;
+        bp = (int)blockIdx.x - slot * nbp;
+        if (slot >= ut.n_ids) return;
+    } else
     if (!(part_major ? part_major_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, ut.pm_group, &slot, &bp) : xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp))) return;
     const UnitRef ur = unit_ref(ut.srec, slot);
     int u = ur.u;
@@ -3608,6 +3617,8 @@ __global__ __launch_bounds__(64) void k_big_zz_fold(UnitTab ut, Pools pl, int tb
 //         per byte: 49 of the 120 ms of the 10000-point unit.
 // ------------------------------------------------------------------------------------------------
 constexpr int BGT = 128, BG_LD = 144, BG_KC = 8, BG_SUPER = 4;
+constexpr int BG_ATSEG = 512;      // rows of [Z | W] per partial product of At (mode 3)
+constexpr int BIG_AT_GEMM_T = 192;  // launches whose largest unit has more tiles per edge (3072 points) form At by mode 3
 
 struct BgOp { const double *A, *B; int lda, ldb, K; double scale; };
 
@@ -3717,6 +3728,22 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
             skip = (wave & 1) == 1;
         }
         bg_accumulate(op, a_ext, b_ext, sm, acc, !skip);
+    } else if (mode == 3) {
+        // At = Z^T W (64 x mp), split over the rows: column tile tj of At, segment sg of BG_ATSEG rows of [Z | W] from the tile's
+        // first row on (W is lower triangular: nothing above) — a partial product per (tile, segment) into the unit's region of
+        // the K pool (free between the substitution and mode 2), slab sg = rows [64 sg, 64 sg + 64) x mp; k_big_at_fold adds the
+        // slabs in segment order.  Only the tile's upper half (64 rows of At) exists: waves 2 and 3 stage and do not compute.
+        const int nsegmax = (BGT * ntmax + BG_ATSEG - 1) / BG_ATSEG;
+        const int tj = x / nsegmax, sg = x - tj * nsegmax;
+        j0 = BGT * tj;
+        const int k_lo = j0 + BG_ATSEG * sg;
+        if (j0 >= mp || k_lo >= mp) return;
+        i0 = 0;
+        a_ext = YPAD; b_ext = mp - j0 < BGT ? mp - j0 : BGT;
+        skip = (wave >> 1) == 1;
+        BgOp op{pl.Z + (b.row_off + (size_t)k_lo) * YPAD, W + (size_t)k_lo * mps + j0, YPAD, mp, mp - k_lo < BG_ATSEG ? mp - k_lo : BG_ATSEG, 1.0};
+        bg_accumulate(op, a_ext, b_ext, sm, acc, !skip);
+        C = pl.K + b.mat_off + (size_t)sg * YPAD * mps + j0; ldc = mp;
     } else {
         const int nt = (mp + BGT - 1) / BGT;
         int tj = 0;
@@ -3742,7 +3769,7 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         double cv[4][4];
-        if (mode != 2) {
+        if (mode < 2) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int cc = cbase + 16 * jj + lr;
@@ -3760,7 +3787,7 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rr = rbase + 16 * ii + lg + 4 * q;
-                if (cc < b_ext && rr < a_ext) C[(size_t)rr * ldc + cc] = mode == 2 ? acc[ii][jj][q] : cv[jj][q] - acc[ii][jj][q];
+                if (cc < b_ext && rr < a_ext) C[(size_t)rr * ldc + cc] = mode >= 2 ? acc[ii][jj][q] : cv[jj][q] - acc[ii][jj][q];
             }
         }
     }
@@ -3770,6 +3797,35 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 // nothing behind them: a second queue, one event per super-block.  One block of 10000 points: 50.5 ms against 40.0 one after the
 // other — the Cholesky's small, latency-critical launches (k_big_diag needs 90 KB of LDS) then wait for a CU to drain behind
 // the other queue's GEMM workgroups.  Removed.)
+// At[i][j] = sum over the segments of column tile j / 128 of the partial products k_big_gemm (mode 3) left in the K pool, in
+// segment order (fixed: the result does not depend on the launch).  grid = (64 rows x column chunks of 256, launch slots)
+__global__ __launch_bounds__(256) void k_big_at_fold(UnitTab ut, Pools pl) {
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, 0, &b)) return;
+    const int i = (int)blockIdx.x & (YPAD - 1), j = 256 * ((int)blockIdx.x >> 6) + (int)threadIdx.x;
+    if (j >= b.mp) return;
+    const size_t mps = (size_t)b.mp;
+    const int j0 = j & ~(BGT - 1);
+    const int nseg = (b.mp - j0 + BG_ATSEG - 1) / BG_ATSEG;
+    const double *slab = pl.K + b.mat_off + (size_t)i * mps + j;
+    double v = 0.0;
+    for (int s0 = 0; s0 < nseg; s0 += 8) {      // (eight slabs in flight)
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = slab[(size_t)(s0 + q < nseg ? s0 + q : s0) * YPAD * mps];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += s0 + q < nseg ? t[q] : 0.0;
+    }
+    pl.At[b.row_off * YPAD + (size_t)i * mps + j] = v;
+}
+// At = Z^T W of the units of more than 1024 points: split-K partial products by the GEMM kernel, then the fold
+void launch_big_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
+    if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
+    const int nt = (16 * ut.max_T + BGT - 1) / BGT, nsegmax = (BGT * nt + BG_ATSEG - 1) / BG_ATSEG;
+    hipLaunchKernelGGL(k_big_gemm, dim3(nt * nsegmax, ut.n_ids), dim3(256), 0, s, ut, p, 3, 0, 0, nt, 0.0);
+    hipLaunchKernelGGL(k_big_at_fold, dim3(YPAD * ((16 * ut.max_T + 255) / 256), ut.n_ids), dim3(256), 0, s, ut, p);
+}
+
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
@@ -4790,16 +4846,22 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T == 0) return;
+    // units of more than 1024 points by the split-K GEMM when the launch's largest has more than BIG_AT_GEMM_T tiles per edge (the
+    // kernels below then leave them alone): below that a unit's longest part is short enough (9 blocks + 20 pairs of n = 10000:
+    // 0.30 ms by k_at, 0.36 by the GEMM, half of whose waves idle on a 64-row tile; ONE block of 10000: 1.16 against 0.28)
+    const bool big_gemm = ut.max_T > BIG_AT_GEMM_T;
+    const int skip_T = big_gemm ? SMALL_MAX_T : MAX_T;
+    if (big_gemm) launch_big_at(ut, p, s);
     // single-unit latency matters while the launch is about one workgroup-round deep (sharded runs); beyond
     // that the wide form's operand reuse wins (C3 on one GPU: 55 vs 58 us, C4: 324 vs 429 us)
     const int cus = device_cus();
     if (ut.n_launch <= cus) {
-        hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p);
+        hipLaunchKernelGGL(k_at, dim3(xcd_grid(ut.n_ids, (ut.max_T + AT_TILES - 1) / AT_TILES)), dim3(256), 0, s, ut, p, skip_T);
         return;
     }
     // ONE round of at most two workgroups per CU: the second resident of a CU in ASCENDING size (largest with smallest)
     const int first_round = (ut.max_T <= 16 && ut.n_ids > cus && ut.n_ids <= 2 * cus) ? cus : 0;
-    hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round);
+    hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round, skip_T);
 }
 
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s) {
