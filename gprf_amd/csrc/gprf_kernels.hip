@@ -3819,6 +3819,10 @@ __global__ __launch_bounds__(256) void k_big_at_fold(UnitTab ut, Pools pl) {
     pl.At[b.row_off * YPAD + (size_t)i * mps + j] = v;
 }
 // At = Z^T W of the units of more than 1024 points: split-K partial products by the GEMM kernel, then the fold
+// block rows per super-block: 4 (256 rows), 8 beyond 4096 points — a GEMM pass has a fixed cost per tile (first fetch, the
+// read-modify-write of C: ~20 % of a K = 256 pass), the 64-row steps inside a super-block grow with its square: one block of
+// 10000 points 31.4 / 30.6 / 30.4 / 30.5 ms at 4 / 6 / 8 / 12, 9 blocks + 20 pairs 10.62 / 10.64 / 10.72 / 11.21 (diag big_super=<n>)
+static int big_super(int max_T) { static const int v = diag("big_super", 0); return v > 0 ? v : (max_T > 256 ? 2 * BG_SUPER : BG_SUPER); }
 void launch_big_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nt = (16 * ut.max_T + BGT - 1) / BGT, nsegmax = (BGT * nt + BG_ATSEG - 1) / BG_ATSEG;
@@ -3831,8 +3835,8 @@ void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipS
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
     hipLaunchKernelGGL(k_big_init, dim3(nbmax * nbmax + nbmax, ut.n_ids), blk, 0, s, ut, p, nbmax, kp.dy);
-    for (int sb0 = 0; sb0 < nbmax; sb0 += BG_SUPER) {
-        const int sb1 = sb0 + BG_SUPER < nbmax ? sb0 + BG_SUPER : nbmax;
+    for (int sb0 = 0; sb0 < nbmax; sb0 += big_super(ut.max_T)) {
+        const int sb1 = sb0 + big_super(ut.max_T) < nbmax ? sb0 + big_super(ut.max_T) : nbmax;
         for (int kb = sb0; kb < sb1; ++kb) {
             hipLaunchKernelGGL(k_big_diag, dim3(ut.n_ids), blk, 0, s, ut, p, kb);
             const int r = nbmax - kb - 1, rin = sb1 - kb - 1;
@@ -3851,8 +3855,8 @@ void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
-    for (int sb0 = 0; sb0 < nbmax; sb0 += BG_SUPER) {
-        const int sb1 = sb0 + BG_SUPER < nbmax ? sb0 + BG_SUPER : nbmax;
+    for (int sb0 = 0; sb0 < nbmax; sb0 += big_super(ut.max_T)) {
+        const int sb1 = sb0 + big_super(ut.max_T) < nbmax ? sb0 + big_super(ut.max_T) : nbmax;
         for (int kb = sb0; kb < sb1; ++kb) {
             hipLaunchKernelGGL(k_big_apply, dim3(kb + 2, ut.n_ids), blk, 0, s, ut, p, kb, 1);
             const int rin = sb1 - kb - 1;
@@ -3903,6 +3907,7 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 //   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-28 tiles on the generic kernel
 //   pipe=<percent>  solve / At / gradient as two pipelines (off)            max_unit=<points>  a lower GPRF_MAX_UNIT (refusal-path tests)
 //   potrf_stamps=1..3  which wave's cycle stamps a -DGPRF_PROFILE build records    grid_hint=0  k_assign scans every centre
+//   big_super=<n>   block rows of 64 per super-block of the blocked path (read once per process)
 // Read at every call (a handful of string searches per evaluation): a test may change it between two contexts of one process.
 int diag(const char *key, int dflt) {
     const char *e = getenv("GPRF_DIAG");

@@ -51,6 +51,30 @@ def test_units_of_1100_and_2200_points_against_the_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("m", [3200, 4240])
+def test_one_unit_beyond_3072_points_against_the_oracle(m):
+    """Launches whose largest unit has more than 3072 points form At = Z^T W by the split-K GEMM (k_big_gemm mode 3 +
+    k_big_at_fold), beyond 4096 points the super-blocks are 512 rows deep: ONE block of 3200 points (200 tiles: mode 3,
+    256-row super-blocks) and of 4240 (265 tiles: 512-row super-blocks, a last super-block of 144 rows) against the oracle's
+    LAPACK path — ll, gradX, gradC."""
+    from gprf_amd import GPCov
+    from gprf_amd.gprf import GPRF
+    rng = np.random.RandomState(m)
+    dy = 5
+    X = rng.rand(m, 2) * [1.6, 1.0]
+    Y = rng.randn(m, dy)
+    blocks = [np.arange(m)]
+    nv, sv, ls = 0.04, 1.2, [0.11, 0.09]
+    g = GPRF(X, Y, None, GPCov([sv], ls, "euclidean", "se"), nv, block_idxs=blocks, neighbors=[])
+    ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+    assert g._ctx.max_T() == (m + 15) // 16
+    o_ll, o_gX, o_gC = _oracle(X, Y, blocks, [], nv, sv, ls).llgrad(grad_X=True, grad_cov=True)
+    assert abs(ll - o_ll) <= 1e-11 * abs(o_ll)
+    assert np.max(np.abs(gX - o_gX)) <= 1e-9 * np.max(np.abs(o_gX))
+    assert np.allclose(gC, o_gC, rtol=1e-8)
+    g.close()
+
+
 def test_lld_matern_unit_of_1100_points_through_the_blocked_path():
     """("lld","matern32") with a block of 1100 events and a pair of 1700: k_fill<lld, matern32>, the blocked Cholesky and
     substitution, M by the LDS-staged GEMM and k_mgrad<lld, matern32, BIG>'s reductions — against the oracle's GPRFRef (the lld
