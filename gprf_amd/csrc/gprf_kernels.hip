@@ -3236,14 +3236,15 @@ void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, d
 //     k_big_diag    U_kk = chol(C_kk) in LDS (one workgroup per unit), V_kk = U_kk^-1, log-det
 //     k_big_apply   U_kj = V_kk^T C_kj                    (row panel, j > k)
 //     k_big_update  C_ij -= U_ki^T U_kj                   (trailing blocks k < i <= j)
-//   forward substitution U^T [W | Z] = [I | Y[rows]], right-looking (W starts as the identity, Z as the gathered outputs):
-//     k_big_apply   [W_kc | Z_k] = V_kk^T [R_kc | R_k]    (c <= k)
-//     k_big_update  [R_ic | R_i] -= U_ki^T [W_kc | Z_k]   (i > k)
-// every product a 64 x 64 x 64 block product in the file's one MFMA form (no transposes: D += SA^T SB with SA, SB row-major
-// and k the slow index), a step's products summed from zero and added once (the hierarchical accumulation of the small
-// kernels, here for free).  At = Z^T W and the gradient reduction are the ordinary kernels (they are tiled over the unit
-// already).  Functional first: operands come straight from L2, nothing is staged — these units are 1e9..1e12 flop each and
-// a launch is thousands of workgroups deep.
+//   forward substitution U^T [W | Z] = [I | Y[rows]], right-looking in super-blocks S (round 5, second half):
+//     k_big_wss_*   W_SS = U_SS^-T, the super-block's diagonal block of W, for EVERY super-block at once (the 64-row steps
+//                   V_kk^T / U_ki^T restricted to the super-block's own columns: 2 sup - 1 launches in all)
+//     k_big_gemm    mode 4:  [W_Sc | Z_S] = W_SS [R_Sc | R_S]   (c < S; R = the running right-hand side, in the K / At pools)
+//                   mode 1:  [R_ic | R_i] -= U_Si^T [W_Sc | Z_S]  (i > S)
+// every small product a 64 x 64 x 64 block product in the file's one MFMA form (no transposes: D += SA^T SB with SA, SB
+// row-major and k the slow index), a step's products summed from zero and added once (the hierarchical accumulation of the
+// small kernels, here for free); everything behind a super-block, At (mode 3) and the gradient matrix M (mode 2) by the
+// LDS-staged GEMM k_big_gemm.
 // ------------------------------------------------------------------------------------------------
 constexpr int BIGB = 64;
 
@@ -3288,6 +3289,7 @@ __device__ __forceinline__ void big_block_mma(const double *__restrict__ SA, int
 
 // K's upper blocks -> U; W = identity (all of it); Z = Y[unit rows], zero padded.
 // grid.x = nbmax * nbmax + nbmax: block (i, j) of the launch-wide block grid, then one workgroup per block row for Z.
+// (the gathered outputs go to the At pool, where the substitution's sweep keeps its running right-hand side: launch_big_solve)
 __global__ __launch_bounds__(256) void k_big_init(UnitTab ut, Pools pl, int nbmax, int dy) {
     BigUnit b;
     if (!big_unit(ut, blockIdx.y, 0, &b)) return;
@@ -3296,7 +3298,7 @@ __global__ __launch_bounds__(256) void k_big_init(UnitTab ut, Pools pl, int nbma
     if (x >= nbmax * nbmax) {
         int bi = x - nbmax * nbmax;
         if (bi >= b.nb) return;
-        double *Z = pl.Z + b.row_off * YPAD;
+        double *Z = pl.At + b.row_off * YPAD;
         const int32_t *upt = ut.upt + b.row_off;
         for (int e = t; e < BIGB * YPAD; e += 256) {
             int row = BIGB * bi + (e >> 6), col = e & 63;
@@ -3448,34 +3450,11 @@ __global__ __launch_bounds__(256) void k_big_diag(UnitTab ut, Pools pl, int kb) 
     }
 }
 
-// X = V_kk^T B in place for a set of blocks of block row kb.  which = 0: the Cholesky's row panel, blocks j = kb+1 .. of U;
-// which = 1: the substitution's row, blocks c = 0 .. kb of W and (blockIdx.x == kb + 1) the rows of Z.
-__global__ __launch_bounds__(256) void k_big_apply(UnitTab ut, Pools pl, int kb, int which) {
-    BigUnit b;
-    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+// B <- V_kk^T B for one block (n x 16 nj, leading dimension ldb) of block row kb; the whole workgroup
+__device__ __forceinline__ void big_apply_block(const Pools &pl, const BigUnit &b, int kb, double *B, int ldb, int nj) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int n = big_rows(b, kb);
-    const size_t mp = (size_t)b.mp;
-    double *B;
-    int ldb, nj;
-    if (which == 0) {
-        int j = kb + 1 + blockIdx.x;
-        if (j >= b.nb) return;
-        B = pl.U + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * j;
-        ldb = b.mp;
-        nj = big_rows(b, j) >> 4;
-    } else if ((int)blockIdx.x <= kb) {
-        B = pl.W + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * blockIdx.x;
-        ldb = b.mp;
-        nj = big_rows(b, blockIdx.x) >> 4;      // (the unit's last block column may be narrower than 64)
-    } else if ((int)blockIdx.x == kb + 1) {
-        B = pl.Z + (b.row_off + (size_t)BIGB * kb) * YPAD;
-        ldb = YPAD;
-        nj = 4;
-    } else {
-        return;
-    }
     const double *Vk = big_vkk(pl, b, kb);
     d4 acc[4];
 #pragma unroll
@@ -3492,51 +3471,10 @@ __global__ __launch_bounds__(256) void k_big_apply(UnitTab ut, Pools pl, int kb,
                 for (int q = 0; q < 4; ++q) B[(size_t)(16 * wave + lg + 4 * q) * ldb + 16 * jt + lr] = acc[jt][q];
     }
 }
-
-// C -= SA^T SB over a set of blocks behind block row kb.  which = 0: the Cholesky's trailing blocks (i, j), kb < i <= j:
-// C = U_ij, SA = U_ki, SB = U_kj; which = 1: the substitution's rows i > kb: C = W_ic (c <= kb) or the rows of Z,
-// SA = U_ki, SB = W_kc or Z_k.  blockIdx.x enumerates the launch-wide block grid (r = nbmax - kb - 1 rows behind kb).
-// i_end: only block rows i < i_end (round 5: the rows INSIDE the current super-block of BG_SUPER block rows; everything
-// behind it takes the super-block's whole contribution at once, k_big_gemm)
-__global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb, int which, int nbmax, int i_end) {
-    BigUnit b;
-    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+// C -= U_ki^T SB for one block (rows of block i x 16 nj): the whole workgroup
+__device__ __forceinline__ void big_update_block(const BigUnit &b, const double *Uk, int kn, int i, double *C, const double *SB, int ldc, int nj) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int kn = big_rows(b, kb);
-    const size_t mp = (size_t)b.mp;
-    const double *Uk = pl.U + b.mat_off + ((size_t)BIGB * kb) * mp;      // block row kb of U
-    int i;
-    double *C;
-    const double *SB;
-    int ldc, nj;
-    if (which == 0) {
-        const int r = nbmax - kb - 1;
-        int x = blockIdx.x, di = 0;
-        while (x >= r - di) { x -= r - di; ++di; }      // row di of the upper block triangle, x columns in
-        i = kb + 1 + di;
-        int j = i + x;
-        if (j >= b.nb || i >= i_end) return;
-        C = pl.U + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * j;
-        SB = Uk + (size_t)BIGB * j;
-        ldc = b.mp;
-        nj = big_rows(b, j) >> 4;
-    } else {
-        const int ncol = kb + 2;
-        i = kb + 1 + (int)blockIdx.x / ncol;
-        int c = (int)blockIdx.x % ncol;
-        if (i >= b.nb || i >= i_end) return;
-        if (c <= kb) {
-            C = pl.W + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * c;
-            SB = pl.W + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * c;
-            ldc = b.mp;
-        } else {
-            C = pl.Z + (b.row_off + (size_t)BIGB * i) * YPAD;
-            SB = pl.Z + (b.row_off + (size_t)BIGB * kb) * YPAD;
-            ldc = YPAD;
-        }
-        nj = 4;
-    }
     if (16 * wave >= big_rows(b, i)) return;
     d4 acc[4];
 #pragma unroll
@@ -3554,6 +3492,58 @@ __global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb
         if (jt < nj)
 #pragma unroll
             for (int q = 0; q < 4; ++q) C[(size_t)(16 * wave + lg + 4 * q) * ldc + 16 * jt + lr] = cv[jt][q] - acc[jt][q];
+}
+
+// W_SS = U_SS^-T, the diagonal super-block of W, of EVERY super-block of every unit at once (blockIdx.z = super-block): the
+// substitution's 64-row steps restricted to the super-block's own columns — step t of `sup`: block row kb = z sup + t.
+// (Round 5, second half: the sweep over the super-blocks then needs no 64-row steps at all — a super-block's rows are ONE product
+// with W_SS, k_big_gemm mode 4 — and these 2 sup - 1 launches are made once, not once per super-block.)
+__global__ __launch_bounds__(256) void k_big_wss_apply(UnitTab ut, Pools pl, int t, int sup) {
+    const int kb = (int)blockIdx.z * sup + t;
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+    const int c = (int)blockIdx.z * sup + (int)blockIdx.x;      // (blockIdx.x = 0 .. t)
+    double *B = pl.W + b.mat_off + ((size_t)BIGB * kb) * b.mp + (size_t)BIGB * c;
+    big_apply_block(pl, b, kb, B, b.mp, big_rows(b, c) >> 4);
+}
+__global__ __launch_bounds__(256) void k_big_wss_update(UnitTab ut, Pools pl, int t, int sup) {
+    const int z0 = (int)blockIdx.z * sup, kb = z0 + t;
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+    const int i = kb + 1 + (int)blockIdx.x / (t + 1), c = z0 + (int)blockIdx.x % (t + 1);      // rows behind kb inside the super-block
+    if (i >= b.nb || i >= z0 + sup) return;
+    const size_t mp = (size_t)b.mp;
+    const double *Uk = pl.U + b.mat_off + ((size_t)BIGB * kb) * mp;
+    double *C = pl.W + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * c;
+    const double *SB = pl.W + b.mat_off + ((size_t)BIGB * kb) * mp + (size_t)BIGB * c;
+    big_update_block(b, Uk, big_rows(b, kb), i, C, SB, b.mp, 4);
+}
+
+// The Cholesky's row panel inside a super-block: U_kj = V_kk^T C_kj in place, blocks j = kb + 1 .. of block row kb.
+__global__ __launch_bounds__(256) void k_big_apply(UnitTab ut, Pools pl, int kb) {
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+    const int j = kb + 1 + blockIdx.x;
+    if (j >= b.nb) return;
+    double *B = pl.U + b.mat_off + ((size_t)BIGB * kb) * b.mp + (size_t)BIGB * j;
+    big_apply_block(pl, b, kb, B, b.mp, big_rows(b, j) >> 4);
+}
+
+// The Cholesky's trailing blocks (i, j), kb < i <= j, i < i_end: U_ij -= U_ki^T U_kj.  blockIdx.x enumerates the launch-wide block
+// grid (r = nbmax - kb - 1 rows behind kb).  i_end: only the block rows INSIDE the current super-block; everything behind it takes
+// the super-block's whole contribution at once (k_big_gemm)
+__global__ __launch_bounds__(256) void k_big_update(UnitTab ut, Pools pl, int kb, int nbmax, int i_end) {
+    BigUnit b;
+    if (!big_unit(ut, blockIdx.y, kb, &b)) return;
+    const size_t mp = (size_t)b.mp;
+    const double *Uk = pl.U + b.mat_off + ((size_t)BIGB * kb) * mp;      // block row kb of U
+    const int r = nbmax - kb - 1;
+    int x = blockIdx.x, di = 0;
+    while (x >= r - di) { x -= r - di; ++di; }      // row di of the upper block triangle, x columns in
+    const int i = kb + 1 + di, j = i + x;
+    if (j >= b.nb || i >= i_end) return;
+    double *C = pl.U + b.mat_off + ((size_t)BIGB * i) * mp + (size_t)BIGB * j;
+    big_update_block(b, Uk, big_rows(b, kb), i, C, Uk + (size_t)BIGB * j, b.mp, big_rows(b, j) >> 4);
 }
 
 // ||Z[:, 16 cb : 16 cb + 16]||_F^2 per column block (the small kernels' zzpart), fixed order: BIG_ZZ_PARTS workgroups per unit sum
@@ -3620,7 +3610,8 @@ constexpr int BGT = 128, BG_LD = 144, BG_KC = 8, BG_SUPER = 4;
 constexpr int BG_ATSEG = 512;      // rows of [Z | W] per partial product of At (mode 3)
 constexpr int BIG_AT_GEMM_T = 192;  // launches whose largest unit has more tiles per edge (3072 points) form At by mode 3
 
-struct BgOp { const double *A, *B; int lda, ldb, K; double scale; };
+// a_trans: the A operand is given transposed — element (k, i) at A[i * lda + k] (mode 4: W_SS read through its transpose)
+struct BgOp { const double *A, *B; int lda, ldb, K; double scale; bool a_trans = false; };
 
 // acc[ii][jj] += scale * sum_k A[k][64 wr + 16 ii + .] B[k][64 wc + 16 jj + .]   (wr, wc = this wave's quadrant)
 __device__ __forceinline__ void bg_accumulate(const BgOp &op, int a_ext, int b_ext, double *sm, d4 (&acc)[4][4], bool compute) {
@@ -3634,8 +3625,10 @@ __device__ __forceinline__ void bg_accumulate(const BgOp &op, int a_ext, int b_e
     // that are never stored — and K is a multiple of BG_KC on every path (multiples of 16).  Written with a select per value,
     // "col_ok && row < K ? load : 0", the compiler fenced every pair of loads with exec branches and s_waitcnt vmcnt(0):
     // four serialised round trips per chunk, the loop ran on the latency of its own prefetch)
-    const double *src0 = (isB ? op.B : op.A) + (col_ok ? col : 0);
-    const int ld = isB ? op.ldb : op.lda;
+    const int colc = col_ok ? col : 0;
+    const bool tr = !isB && op.a_trans;
+    const double *src0 = isB ? op.B + colc : (tr ? op.A + (size_t)colc * op.lda : op.A + colc);
+    const size_t ld = tr ? (size_t)1 : (size_t)(isB ? op.ldb : op.lda);      // distance between consecutive k
     const int nch = op.K / BG_KC;
     double pre0[BG_KC], pre1[BG_KC];
     auto fetch = [&](int c, double (&pre)[BG_KC]) {
@@ -3690,6 +3683,7 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
     int i0, j0, ldc, a_ext, b_ext;
     double *C;
     bool skip = false;      // this wave's quadrant is not wanted
+    int store = mode >= 2 ? 1 : 0;      // how the tile enters C: 0 = C -= acc, 1 = C = acc, 2 = C = -acc
     d4 acc[4][4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -3716,14 +3710,43 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
         if (di >= nt) return;
         i0 = r0 + BGT * di;
         a_ext = mp - i0 < BGT ? mp - i0 : BGT;
+        // (round 5, second half: the RUNNING right-hand sides R live outside the result pools — the W columns' in the unit's
+        // region of the K pool, which the factorisation has left, the Z columns' in the At pool, which nobody needs before the
+        // substitution is over — because a super-block's rows are now solved by ONE product with its inverse diagonal block
+        // (mode 4), which cannot run in place.  A tile of R whose columns belong to THIS super-block has no earlier term: it
+        // is written, not updated — nobody has to zero 800 MB first.)
         BgOp op{U + (size_t)k0 * mps + i0, nullptr, mp, mp, r0 - k0, 1.0};
         if (c < ncol - 1) {
             j0 = BGT * c; b_ext = BGT;
             op.B = W + (size_t)k0 * mps + j0;
-            C = W + (size_t)i0 * mps + j0; ldc = mp;
+            C = pl.K + b.mat_off + (size_t)i0 * mps + j0; ldc = mp;
+            if (j0 >= k0) store = 2;
         } else {
             j0 = 0; b_ext = YPAD;
             op.B = pl.Z + (b.row_off + (size_t)k0) * YPAD; op.ldb = YPAD;
+            C = pl.At + (b.row_off + (size_t)i0) * YPAD; ldc = YPAD;
+            skip = (wave & 1) == 1;
+        }
+        bg_accumulate(op, a_ext, b_ext, sm, acc, !skip);
+    } else if (mode == 4) {
+        // the super-block's own rows of [W | Z]:  X_S = W_SS R_S  with W_SS = U_SS^-T, the super-block's diagonal block of W
+        // (k_big_wss_*: every super-block's at once, before the sweep) — row tile ra of the super-block (128 rows) x column tile
+        // c of the columns in front of it (c = ncol: the Z columns).  W_SS is lower triangular: K = the rows up to this tile's last.
+        if (k0 >= mp) return;
+        const int rows = (r0 < mp ? r0 : mp) - k0;                 // of this unit's super-block
+        const int ncol = k0 / BGT, nrt = (BIGB * (sb1 - sb0) + BGT - 1) / BGT;
+        const int ra = x % nrt, c = x / nrt;
+        if (BGT * ra >= rows || c > ncol) return;
+        i0 = k0 + BGT * ra;
+        a_ext = rows - BGT * ra < BGT ? rows - BGT * ra : BGT;
+        BgOp op{W + (size_t)i0 * mps + k0, nullptr, mp, mp, BGT * ra + a_ext, 1.0, true};
+        if (c < ncol) {
+            j0 = BGT * c; b_ext = BGT;
+            op.B = pl.K + b.mat_off + (size_t)k0 * mps + j0;
+            C = W + (size_t)i0 * mps + j0; ldc = mp;
+        } else {
+            j0 = 0; b_ext = YPAD;
+            op.B = pl.At + (b.row_off + (size_t)k0) * YPAD; op.ldb = YPAD;
             C = pl.Z + (b.row_off + (size_t)i0) * YPAD; ldc = YPAD;
             skip = (wave & 1) == 1;
         }
@@ -3769,7 +3792,7 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         double cv[4][4];
-        if (mode < 2) {
+        if (store == 0) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int cc = cbase + 16 * jj + lr;
@@ -3787,7 +3810,8 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rr = rbase + 16 * ii + lg + 4 * q;
-                if (cc < b_ext && rr < a_ext) C[(size_t)rr * ldc + cc] = mode >= 2 ? acc[ii][jj][q] : cv[jj][q] - acc[ii][jj][q];
+                if (cc < b_ext && rr < a_ext)
+                    C[(size_t)rr * ldc + cc] = store == 1 ? acc[ii][jj][q] : (store == 2 ? -acc[ii][jj][q] : cv[jj][q] - acc[ii][jj][q]);
             }
         }
     }
@@ -3822,7 +3846,7 @@ __global__ __launch_bounds__(256) void k_big_at_fold(UnitTab ut, Pools pl) {
 // block rows per super-block: 4 (256 rows), 8 beyond 4096 points — a GEMM pass has a fixed cost per tile (first fetch, the
 // read-modify-write of C: ~20 % of a K = 256 pass), the 64-row steps inside a super-block grow with its square: one block of
 // 10000 points 31.4 / 30.6 / 30.4 / 30.5 ms at 4 / 6 / 8 / 12, 9 blocks + 20 pairs 10.62 / 10.64 / 10.72 / 11.21 (diag big_super=<n>)
-static int big_super(int max_T) { static const int v = diag("big_super", 0); return v > 0 ? v : (max_T > 256 ? 2 * BG_SUPER : BG_SUPER); }
+static int big_super(int max_T) { static const int v = diag("big_super", 0); return v > 0 ? (v + 1) & ~1 : (max_T > 256 ? 2 * BG_SUPER : BG_SUPER); }      // (even: a super-block starts on a 128-column tile)
 void launch_big_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nt = (16 * ut.max_T + BGT - 1) / BGT, nsegmax = (BGT * nt + BG_ATSEG - 1) / BG_ATSEG;
@@ -3840,9 +3864,9 @@ void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipS
         for (int kb = sb0; kb < sb1; ++kb) {
             hipLaunchKernelGGL(k_big_diag, dim3(ut.n_ids), blk, 0, s, ut, p, kb);
             const int r = nbmax - kb - 1, rin = sb1 - kb - 1;
-            if (r > 0) hipLaunchKernelGGL(k_big_apply, dim3(r, ut.n_ids), blk, 0, s, ut, p, kb, 0);
+            if (r > 0) hipLaunchKernelGGL(k_big_apply, dim3(r, ut.n_ids), blk, 0, s, ut, p, kb);
             // the rows inside the super-block: the first rin rows of the upper block triangle behind kb
-            if (rin > 0) hipLaunchKernelGGL(k_big_update, dim3(rin * r - rin * (rin - 1) / 2, ut.n_ids), blk, 0, s, ut, p, kb, 0, nbmax, sb1);
+            if (rin > 0) hipLaunchKernelGGL(k_big_update, dim3(rin * r - rin * (rin - 1) / 2, ut.n_ids), blk, 0, s, ut, p, kb, nbmax, sb1);
         }
         if (sb1 < nbmax) {
             const int nt = (BIGB * (nbmax - sb1) + BGT - 1) / BGT;
@@ -3855,21 +3879,34 @@ void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
     if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
-    for (int sb0 = 0; sb0 < nbmax; sb0 += big_super(ut.max_T)) {
-        const int sb1 = sb0 + big_super(ut.max_T) < nbmax ? sb0 + big_super(ut.max_T) : nbmax;
-        for (int kb = sb0; kb < sb1; ++kb) {
-            hipLaunchKernelGGL(k_big_apply, dim3(kb + 2, ut.n_ids), blk, 0, s, ut, p, kb, 1);
-            const int rin = sb1 - kb - 1;
-            if (rin > 0) hipLaunchKernelGGL(k_big_update, dim3(rin * (kb + 2), ut.n_ids), blk, 0, s, ut, p, kb, 1, nbmax, sb1);
+    // The sweep's super-blocks (block rows of 64; even): deeper than the factorisation's where the units are large — nothing
+    // inside a super-block costs launches here.  Substitution of ONE block of 10000 points / 9 blocks + 20 pairs / one block of
+    // 4000, ms: 12.8 / 3.75 / 2.17 at 2, 10.6 / 3.35 / 1.80 at 4, 9.85 / 3.27 / 1.73 at 6, 9.6 / 3.5 / 1.63 at 8, 9.25 / 3.43 /
+    // 1.71 at 12, 9.7 / 3.8 / 1.58 at 16 (diag big_super_solve=<n>); with the 64-row steps inside every super-block (the round's
+    // first half, super-blocks as the factorisation's): 10.34 / 3.54 / 1.72.
+    static const int sup_diag = diag("big_super_solve", 0);
+    const int sup = sup_diag > 0 ? (sup_diag + 1) & ~1 : (ut.max_T > 512 ? 12 : (ut.max_T > 192 ? 8 : 6));
+    {
+        // W_SS = U_SS^-T of every super-block at once (2 sup - 1 small launches in all), then the sweep: per super-block ONE
+        // product X_S = W_SS R_S (mode 4; R in the K pool, the Z columns' in the At pool) and the update of everything behind it
+        const int nsb = (nbmax + sup - 1) / sup;
+        for (int t = 0; t < sup; ++t) {
+            hipLaunchKernelGGL(k_big_wss_apply, dim3(t + 1, ut.n_ids, nsb), blk, 0, s, ut, p, t, sup);
+            if (t + 1 < sup) hipLaunchKernelGGL(k_big_wss_update, dim3((sup - 1 - t) * (t + 1), ut.n_ids, nsb), blk, 0, s, ut, p, t, sup);
         }
-        if (sb1 < nbmax) {
-            const int nt = (BIGB * (nbmax - sb1) + BGT - 1) / BGT;
-            hipLaunchKernelGGL(k_big_gemm, dim3(nt * (sb1 / 2 + 1), ut.n_ids), blk, 0, s, ut, p, 1, sb0, sb1, nt, 0.0);
+        for (int sb0 = 0; sb0 < nbmax; sb0 += sup) {
+            const int sb1 = sb0 + sup < nbmax ? sb0 + sup : nbmax;
+            const int nrt = (BIGB * (sb1 - sb0) + BGT - 1) / BGT, ncol = BIGB * sb0 / BGT;
+            hipLaunchKernelGGL(k_big_gemm, dim3(nrt * (ncol + 1), ut.n_ids), blk, 0, s, ut, p, 4, sb0, sb1, 0, 0.0);
+            if (sb1 < nbmax) {
+                const int nt = (BIGB * (nbmax - sb1) + BGT - 1) / BGT;
+                hipLaunchKernelGGL(k_big_gemm, dim3(nt * (sb1 / 2 + 1), ut.n_ids), blk, 0, s, ut, p, 1, sb0, sb1, nt, 0.0);
+            }
         }
+        const int tbs = (ut.max_T + 3) / 4;
+        hipLaunchKernelGGL(k_big_zz, dim3(BIG_ZZ_PARTS, ut.n_ids), blk, 0, s, ut, p, tbs);
+        hipLaunchKernelGGL(k_big_zz_fold, dim3(ut.n_ids), dim3(64), 0, s, ut, p, tbs);
     }
-    const int tbs = (ut.max_T + 3) / 4;
-    hipLaunchKernelGGL(k_big_zz, dim3(BIG_ZZ_PARTS, ut.n_ids), blk, 0, s, ut, p, tbs);
-    hipLaunchKernelGGL(k_big_zz_fold, dim3(ut.n_ids), dim3(64), 0, s, ut, p, tbs);
 }
 
 // ------------------------------------------------------------------------------------------------
