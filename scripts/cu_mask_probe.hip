@@ -1,6 +1,6 @@
-// Does a CU-masked stream confine a kernel's workgroups (hipExtStreamCreateWithCUMask)?  Prints the distinct (XCC, SE, CU) a
-// 512-workgroup launch ran on, for an unmasked stream and for masks of 8 / 248 CUs, and the time of a busy kernel on each.
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/cu_mask_probe scripts/cu_mask_probe.hip && /tmp/cu_mask_probe
+// How does hipExtStreamCreateWithCUMask number the CUs of an MI355X?  For a mask with ONE bit set (bit b of 256) the kernel
+// below reports which (XCC, SE, CU) its 2048 workgroups ran on; then the times of a busy kernel under masks of 8 / 32 / 248 bits.
+//   hipcc --offload-arch=gfx950 -O2 -w -o /tmp/cu_mask_probe scripts/cu_mask_probe.hip && /tmp/cu_mask_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <set>
@@ -11,31 +11,44 @@ __global__ void k(unsigned *out, int spin) {
     for (int i = 0; i < spin; ++i) x = x * 1.0000001 + 1e-9;
     if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 0xf) << 16) | (hw & 0xffff) | (x < 0 ? 1u << 31 : 0);
 }
-static void run(const char *name, hipStream_t s, unsigned *d, int n) {
+static std::set<unsigned> where(hipStream_t s, unsigned *d, int n, float *ms_out, int spin) {
     std::vector<unsigned> h(n);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k, dim3(n), dim3(256), 0, s, d, 2000);
     hipEventRecord(e0, s);
-    hipLaunchKernelGGL(k, dim3(n), dim3(256), 0, s, d, 20000);
+    hipLaunchKernelGGL(k, dim3(n), dim3(256), 0, s, d, spin);
     hipEventRecord(e1, s);
     hipStreamSynchronize(s);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) hipEventElapsedTime(ms_out, e0, e1);
     hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost);
     std::set<unsigned> cus;
-    for (unsigned v : h) cus.insert(((v >> 16) & 0xf) << 12 | ((v >> 8) & 0xf) << 4 | ((v >> 13) & 0x7) << 8);   // xcc | cu_id(bits 8-11) | se_id(bits 13-15)
-    printf("%-22s distinct (xcc, se, cu): %3zu   busy kernel %.3f ms\n", name, cus.size(), ms);
+    for (unsigned v : h) cus.insert((((v >> 16) & 0xf) << 8) | (((v >> 13) & 0x7) << 4) | ((v >> 8) & 0xf));   // xcc | se | cu
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return cus;
 }
 int main() {
     const int n = 2048;
     unsigned *d; hipMalloc(&d, n * 4);
-    hipStream_t s0, s8, s248;
-    hipStreamCreate(&s0);
-    uint32_t m8[8] = {0}, m248[8];
-    for (int i = 0; i < 8; ++i) { m8[i] = 1u; m248[i] = ~1u; }      // bit 0 of every 32-bit word / everything else
-    hipError_t r1 = hipExtStreamCreateWithCUMask(&s8, 8, m8), r2 = hipExtStreamCreateWithCUMask(&s248, 8, m248);
-    printf("create masked streams: %s / %s\n", hipGetErrorString(r1), hipGetErrorString(r2));
-    run("unmasked", s0, d, n);
-    if (r1 == hipSuccess) run("mask: 8 bits", s8, d, n);
-    if (r2 == hipSuccess) run("mask: 248 bits", s248, d, n);
+    for (int b = 0; b < 256; b += (b < 40 ? 1 : 37)) {
+        uint32_t m[8] = {0};
+        m[b >> 5] = 1u << (b & 31);
+        hipStream_t s;
+        if (hipExtStreamCreateWithCUMask(&s, 8, m) != hipSuccess) { printf("bit %d: create failed\n", b); continue; }
+        std::set<unsigned> c = where(s, d, n, nullptr, 200);
+        printf("bit %3d -> %zu CUs:", b, c.size());
+        int cnt = 0;
+        for (unsigned v : c) if (cnt++ < 10) printf(" (x%u s%u c%u)", v >> 8, (v >> 4) & 7, v & 15);
+        printf("\n");
+        hipStreamDestroy(s);
+    }
+    struct { const char *name; int nbits; } tests[] = {{"8 bits (0..7)", 8}, {"32 bits (0..31)", 32}, {"248 bits (8..255)", -248}, {"256 bits", 256}};
+    for (auto &t : tests) {
+        uint32_t m[8] = {0};
+        for (int b = 0; b < 256; ++b) { bool on = t.nbits > 0 ? b < t.nbits : b >= 8; if (on) m[b >> 5] |= 1u << (b & 31); }
+        hipStream_t s; hipExtStreamCreateWithCUMask(&s, 8, m);
+        float ms; where(s, d, n, nullptr, 2000);
+        std::set<unsigned> c = where(s, d, n, &ms, 20000);
+        printf("%-18s %3zu CUs, busy kernel %.3f ms\n", t.name, c.size(), ms);
+        hipStreamDestroy(s);
+    }
     return 0;
 }
