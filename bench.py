@@ -40,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak (vendor data sheet; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): clock under load
+FP64_MFMA_MEASURED_TFLOPS = 47.8   # scripts/mfma_f64_peak.hip on the box (profiles/r01_mfma_f64_peak.txt): the all-MFMA micro-benchmark, clock lowered under that load (a real kernel exceeds it: k_big_gemm's long-K pass 56)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 STAGE_PASS_EVALS = 60     # evaluations of the separate pass that times every kernel of every evaluation
