@@ -73,3 +73,34 @@ def test_potrf_reg_accumulators_are_untouched_by_the_compiler(isa, inst, slots):
 def test_generic_potrf_does_not_spill(isa):
     body = _function(isa, "7k_potrfENS")
     assert not [l for l in body if "scratch_" in l]
+
+
+def _longest_exposed_run(body):
+    """scripts/isa_serial_loads.py's figure: the longest run of [vector loads, s_waitcnt vmcnt(0)] groups with no MFMA or
+    barrier in between — memory round trips that nothing overlaps."""
+    chain = best = 0
+    pending = False
+    for l in body:
+        s = l.strip()
+        if s.startswith(("global_load", "buffer_load", "flat_load")) and "lds" not in s.split()[0]:
+            pending = True
+        elif s.startswith("s_waitcnt") and "vmcnt(0)" in s:
+            if pending:
+                chain += 1
+                best = max(best, chain)
+                pending = False
+        elif s.startswith(("v_mfma", "s_barrier")):
+            chain = 0
+    return best
+
+
+def test_blocked_path_gemm_keeps_its_loads_in_flight(isa):
+    """Round 5: k_big_gemm's operand fetch (a select around every load) and its epilogue (element-wise C -= acc) had compiled to
+    load / s_waitcnt vmcnt(0) / load chains — 65 exposed round trips in a row, 39.9 ms instead of 33.6 for the 10000-point
+    unit.  The branch-free fetch and the batched epilogue must stay that way: a handful of waits, and
+    the chunk loop's prefetch outstanding across its barrier (a counted vmcnt, not 0)."""
+    body = _function(isa, "10k_big_gemmENS")
+    assert _longest_exposed_run(body) <= 8
+    assert any(re.search(r"s_waitcnt vmcnt\((8|9|1\d)\)", l) for l in body)      # eight loads stay in flight behind the wait
+    assert not [l for l in body if "scratch_" in l]
+    assert _longest_exposed_run(_function(isa, "12k_big_updateENS")) <= 2
