@@ -355,7 +355,7 @@ int reserve_workspace(gprf_ctx *c, int64_t rows, int64_t mat, int maxT) {
     HIP_TRY(c, c->d_U.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
     HIP_TRY(c, c->d_W.reserve((size_t)mat + GPRF_POOL_SLACK, 1.0));
     HIP_TRY(c, c->d_V.reserve((size_t)rows * 16 + 1, 1.0));
-    if (maxT > SMALL_MAX_T) HIP_TRY(c, c->d_Vb.reserve(((size_t)rows + 64 * nl1 + 64) * 64, 1.0));
+    if (maxT > BIG_LA_T) HIP_TRY(c, c->d_Vb.reserve(((size_t)rows + 64 * nl1 + 64) * 64, 1.0));
     HIP_TRY(c, c->d_Xu.reserve((size_t)rows * 8 + 1, 1.0));      // XPAD, or 8 for the lld record
     HIP_TRY(c, c->d_Z.reserve((size_t)rows * YPAD + 1, 1.0));
     HIP_TRY(c, c->d_At.reserve((size_t)rows * YPAD + 1, 1.0));

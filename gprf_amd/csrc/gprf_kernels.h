@@ -11,6 +11,9 @@ constexpr int MAX_MP = 16384;      // largest padded unit (GPRF_MAX_UNIT)
 constexpr int MAX_T = MAX_MP / TILE;
 constexpr int SMALL_MAX_T = 64;    // units of up to 64 tiles per edge (1024 points) run one workgroup per unit and stage; larger
                                    // ones ("big" units) go through the blocked multi-launch path (k_big_*)
+constexpr int BIG_LA_T = 32;       // units of more than 32 tiles per edge (512 points): Cholesky and forward substitution by the blocked
+                                   // path already (k_solve_panel's limit) — 25 blocks + 72 pairs of n = 10000 (pairs of ~800 points):
+                                   // 5.3 -> 3.4 ms per evaluation; their At and gradient stay with k_at / k_mgrad up to SMALL_MAX_T
 constexpr int YPAD = 64;          // dy padded to 4 column tiles
 constexpr int XPAD = 4;           // dx padded (dx <= 3)
 constexpr int GC_SLOTS = 8;       // per-(unit, column-tile) hyper-gradient partials

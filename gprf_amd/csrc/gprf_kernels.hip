@@ -853,7 +853,7 @@ __global__ __launch_bounds__(POTRF_WAVES * 64, 4) void k_potrf(UnitTab ut, Pools
         return;
     }
     int mp = pad16(m), T = mp >> 4;
-    if (T <= reg_maxT || T > SMALL_MAX_T) return;            // k_potrf_reg's units; the blocked path's (k_big_*)
+    if (T <= reg_maxT || T > BIG_LA_T) return;               // k_potrf_reg's units; the blocked path's (k_big_*)
     int ldp = mp + ((T & 1) ? 0 : 16);
     double *P = lds;                      // [16][ldp] row panel j of U
     double *Ud = P + 16 * ldp;            // [16][16]  U_jj
@@ -1914,115 +1914,10 @@ __global__ __launch_bounds__(RW * 64, 2) __attribute__((amdgpu_num_vgpr(96))) vo
 
 // ------------------------------------------------------------------------------------------------
 // Forward substitution  U^T [W | Z] = [I | Y[unit rows]]  (replaces dtrtri/dpotri/dpotrs of gpy_linalg.py:219-253,
-// 139-148): one workgroup per 16-column block of the right-hand side, right-looking, the block's
-// running tiles live in MFMA accumulators; only the freshly solved tile goes through LDS.
-// blockIdx.x < max_T : identity column block cb (rows >= cb only, W is lower triangular)
-// blockIdx.x >= max_T: Y column block yb = blockIdx.x - max_T (all rows)
+// 139-148), right-looking.  Units of up to 32 tiles per edge: k_solve_panel below; larger ones: the blocked path
+// (launch_big_solve).  (Rounds 1-5 also had a generic one-workgroup-per-column-block kernel, k_solve, for units of 33 .. 64
+// tiles: 2.0 ms for the 25-block run's pairs of ~800 points against 1.07 by the blocked path; removed.)
 // ------------------------------------------------------------------------------------------------
-constexpr int SOLVE_WAVES = 4;
-constexpr int SOLVE_SLOTS = SMALL_MAX_T / SOLVE_WAVES;  // 16 accumulator tiles per wave: units of up to 1024 points
-
-__global__ __launch_bounds__(SOLVE_WAVES * 64) void k_solve(UnitTab ut, Pools pl, int dy) {
-    __shared__ double Wr[2][256];
-    __shared__ double zred[SOLVE_WAVES];
-    const UnitRef ur = unit_ref(ut.srec, blockIdx.y);
-    int u = ur.u;
-    int m = ur.m;
-    int mp = pad16(m), T = mp >> 4;
-    if (T > SMALL_MAX_T) return;          // the blocked path's units (launch_big_solve)
-    int bx = blockIdx.x;
-    bool is_y = bx >= ut.max_T;
-    int cb = is_y ? (bx - ut.max_T) : bx;
-    if (!is_y && cb >= T) return;
-    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar wave index
-    int lr = lane & 15, lg = lane >> 4;
-    size_t roff = ur.row_off;
-    if (T == 0) {
-        if (is_y && threadIdx.x == 0) pl.zzpart[(size_t)u * 4 + cb] = 0.0;
-        return;
-    }
-    const double *U = pl.U + ur.mat_off;
-    const double *V = pl.V + roff * 16;
-    double *W = pl.W + ur.mat_off;
-    double *Z = pl.Z + roff * YPAD;
-    const int32_t *upt = ut.upt + roff;
-    int r0 = is_y ? 0 : cb;
-
-    d4 acc[SOLVE_SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
-        int r = r0 + wave + SOLVE_WAVES * sl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double v = 0.0;
-            if (r < T) {
-                if (is_y) {
-                    int row = 16 * r + lg + 4 * q, col = 16 * cb + lr;     // Y[unit rows]: gathered here, zero padded
-                    if (row < m && col < dy) v = pl.Y[(size_t)upt[row] * dy + col];
-                } else {
-                    v = (r == cb && (lg + 4 * q) == lr) ? 1.0 : 0.0;
-                }
-            }
-            acc[sl][q] = v;
-        }
-    }
-    double zz = 0.0;
-    for (int r = r0; r < T; ++r) {
-        int owner = (r - r0) & (SOLVE_WAVES - 1);
-        int slot = (r - r0) / SOLVE_WAVES;
-        double *buf = Wr[r & 1];
-        if (wave == owner) {
-            const double *Vr = V + (size_t)r * 256;
-            d4 w = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
-                if (sl == slot) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) w = mfma(Vr[(4 * s + lg) * 16 + lr], acc[sl][s], w);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                buf[(lg + 4 * q) * 16 + lr] = w[q];
-                if (is_y) {
-                    Z[(size_t)(16 * r + lg + 4 * q) * YPAD + 16 * cb + lr] = w[q];
-                    zz += w[q] * w[q];
-                } else {
-                    W[(size_t)(16 * r + lg + 4 * q) * mp + 16 * cb + lr] = w[q];
-                }
-            }
-        }
-        __syncthreads();
-        // update the rows below: acc_r' -= U_{r,r'}^T W_r
-        double b[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = buf[(4 * s + lg) * 16 + lr];
-#pragma unroll
-        for (int sl = 0; sl < SOLVE_SLOTS; ++sl) {
-            int rp = r0 + wave + SOLVE_WAVES * sl;
-            if (rp > r && rp < T) {
-                const double *Urr = U + (size_t)(16 * r) * mp + 16 * rp;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    double a = -Urr[(size_t)(4 * s + lg) * mp + lr];
-                    acc[sl] = mfma(a, b[s], acc[sl]);
-                }
-            }
-        }
-    }
-    if (is_y) {
-        // ||Z[:, 16cb:16cb+16]||_F^2, fixed reduction order
-        for (int off = 32; off >= 1; off >>= 1) zz += shfl_xor_d(zz, off);
-        if (lane == 0) zred[wave] = zz;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int w = 0; w < SOLVE_WAVES; ++w) t += zred[w];
-            pl.zzpart[(size_t)u * 4 + cb] = t;
-        }
-    }
-}
-
 
 constexpr int SOLVE_PANEL_MAXT = 32;  // largest k_solve_panel instantiation (accumulators: 32 tiles x 8 registers, two panels
                                       // of 31 tile columns = 127 KB of LDS, one workgroup per CU: units of up to 512 points)
@@ -2062,6 +1957,7 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     int u = ur.u;
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
+    if (T > BIG_LA_T) return;                    // (uniform) the blocked path's units (launch_big_solve)
     int tid = threadIdx.x;
     int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
     int lr = lane & 15, lg = lane >> 4;
@@ -3250,11 +3146,12 @@ constexpr int BIGB = 64;
 
 struct BigUnit { int u, m, mp, nb; size_t mat_off; size_t row_off; };
 // the unit of launch slot `slot` if it is a big one and has a block row kb
-__device__ __forceinline__ bool big_unit(const UnitTab &ut, int slot, int kb, BigUnit *b) {
+// min_T: BIG_LA_T for the Cholesky / substitution kernels, SMALL_MAX_T for what serves At and the gradient (modes 2, 3)
+__device__ __forceinline__ bool big_unit(const UnitTab &ut, int slot, int kb, BigUnit *b, int min_T = BIG_LA_T) {
     const UnitRef ur = unit_ref(ut.srec, slot);
     b->u = ur.u; b->m = ur.m; b->mp = pad16(ur.m); b->mat_off = ur.mat_off; b->row_off = (size_t)ur.row_off;
     b->nb = (b->mp + BIGB - 1) / BIGB;
-    return (b->mp >> 4) > SMALL_MAX_T && kb < b->nb;
+    return (b->mp >> 4) > min_T && kb < b->nb;
 }
 __device__ __forceinline__ int big_rows(const BigUnit &b, int blk) { int r = b.mp - BIGB * blk; return r < BIGB ? r : BIGB; }
 // where a unit's V_kk blocks live in Pools::Vb
@@ -3673,7 +3570,7 @@ __device__ __forceinline__ void bg_accumulate(const BgOp &op, int a_ext, int b_e
 __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int mode, int sb0, int sb1, int ntmax, double dy) {
     __shared__ double sm[2 * 2 * BG_KC * BG_LD];
     BigUnit b;
-    if (!big_unit(ut, blockIdx.y, 0, &b)) return;
+    if (!big_unit(ut, blockIdx.y, 0, &b, (mode == 2 || mode == 3) ? SMALL_MAX_T : BIG_LA_T)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int mp = b.mp;
@@ -3825,7 +3722,7 @@ __global__ __launch_bounds__(256, 2) void k_big_gemm(UnitTab ut, Pools pl, int m
 // segment order (fixed: the result does not depend on the launch).  grid = (64 rows x column chunks of 256, launch slots)
 __global__ __launch_bounds__(256) void k_big_at_fold(UnitTab ut, Pools pl) {
     BigUnit b;
-    if (!big_unit(ut, blockIdx.y, 0, &b)) return;
+    if (!big_unit(ut, blockIdx.y, 0, &b, SMALL_MAX_T)) return;
     const int i = (int)blockIdx.x & (YPAD - 1), j = 256 * ((int)blockIdx.x >> 6) + (int)threadIdx.x;
     if (j >= b.mp) return;
     const size_t mps = (size_t)b.mp;
@@ -3855,7 +3752,7 @@ void launch_big_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
 }
 
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
-    if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
+    if (ut.n_ids == 0 || ut.max_T <= BIG_LA_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
     hipLaunchKernelGGL(k_big_init, dim3(nbmax * nbmax + nbmax, ut.n_ids), blk, 0, s, ut, p, nbmax, kp.dy);
@@ -3876,7 +3773,7 @@ void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipS
 }
 
 void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s) {
-    if (ut.n_ids == 0 || ut.max_T <= SMALL_MAX_T) return;
+    if (ut.n_ids == 0 || ut.max_T <= BIG_LA_T) return;
     const int nbmax = (16 * ut.max_T + BIGB - 1) / BIGB;
     dim3 blk(256);
     // The sweep's super-blocks (block rows of 64; even): deeper than the factorisation's where the units are large — nothing
@@ -4764,7 +4661,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
             reg_maxT = POTRF_REG8W_MAXT;
             if (ut.max_T <= reg_maxT) return;
         }
-        const int capG = ut.max_T < SMALL_MAX_T ? ut.max_T : SMALL_MAX_T;      // (larger units: launch_big_potrf)
+        const int capG = ut.max_T < BIG_LA_T ? ut.max_T : BIG_LA_T;      // (larger units: launch_big_potrf)
         size_t ldsg = (size_t)(16 * (16 * capG + 16) + 256 + 16 + 16 * 17 + 256 + 16 * capG) * sizeof(double);
         if (lds_needs_optin(1, ldsg))
             (void)hipFuncSetAttribute((const void *)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
@@ -4836,7 +4733,8 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     launch_generic();
 }
 
-void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s) {
+void launch_solve(const UnitTab &ut_all, const Pools &p, const KParams &kp, hipStream_t s) {
+    const UnitTab &ut = ut_all;
     if (ut.n_ids == 0) return;
     // PM: the grid walked part by part (part_major_map) — launches at most two rounds of CUs wide; diag part_major=0 / 1 forces
     const int pm_d = diag("part_major", -1);
@@ -4844,7 +4742,11 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
     // (GPRF_ONLY_POTRF: tests/test_isa_invariants.py compiles this file for the Cholesky kernels' ISA alone — the dozen
     // unrolled k_solve_panel / k_mgrad instantiations are two thirds of the compile time)
 #ifndef GPRF_ONLY_POTRF
-    if (ut.max_T <= SOLVE_PANEL_MAXT) {
+    static_assert(BIG_LA_T <= SOLVE_PANEL_MAXT, "every unit the blocked path leaves alone fits a k_solve_panel instantiation");
+    {
+        // (the launch's units of more than BIG_LA_T tiles go through launch_big_solve; the instantiation follows the others)
+        UnitTab ut = ut_all;
+        if (ut.max_T > BIG_LA_T) ut.max_T = BIG_LA_T;
         const int nparts = (ut.max_T + 3) / 4 + 1;
         dim3 grid(xcd_grid(ut.n_ids, nparts));
         UnitTab utp = ut;
@@ -4876,14 +4778,8 @@ void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStrea
             else                          // (units of up to 512 points, one workgroup per CU)
                 hipLaunchKernelGGL((k_solve_panel<SOLVE_PANEL_MAXT, 1, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
         }
-        return;
     }
 #endif
-    // units of more than 512 points: accumulators no longer fit the register budget -> LDS-broadcast form
-    // (its grid covers units of up to 1024 points; larger ones are skipped here: launch_big_solve)
-    UnitTab uts = ut;
-    if (uts.max_T > SMALL_MAX_T) uts.max_T = SMALL_MAX_T;
-    hipLaunchKernelGGL(k_solve, dim3(uts.max_T + 4, ut.n_ids), dim3(SOLVE_WAVES * 64), 0, s, uts, p, kp.dy);
 }
 
 void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
@@ -4928,6 +4824,9 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     dim3 grid(pm && G > 0 ? ((ut.n_ids + G - 1) / G) * G * nbp : xcd_grid(ut.n_ids, nbp));
     UnitTab utp = ut;
     utp.pm_group = G;
+    // (a launch with units of more than BIG_LA_T tiles: their regions of the K pool have been the blocked substitution's scratch
+    // — every kernel value is re-evaluated)
+    if (ut.max_T > BIG_LA_T) have_K = false;
     if (dist_id == 0 && kern_id == 0) {
         // 0: general; 1: at most two input dimensions, no hyper-parameter gradient; 2: two dimensions with it
         const int fast = kp.dx <= 2 ? (want_gc ? 2 : 1) : 0;
