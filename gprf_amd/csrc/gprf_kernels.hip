@@ -1163,9 +1163,9 @@ constexpr int POTRF_REG_MAXT_C = 16;  // largest unit edge in tiles the four-wav
 // 30 in row-major order (row 0 and part of row 1: they retire first and are updated at most once) wait in LDS
 constexpr int POTRF_REG8_MAXT = 20;
 constexpr int POTRF_REG8_LDP = 336;  // >= 16 * 20, = 16 mod 32
-// ... and 21 .. 28 tiles (GW): the tiles beyond the 160 accumulator slots wait in the U pool, at their own place
-constexpr int POTRF_REG8W_MAXT = 28;
-constexpr int POTRF_REG8W_LDP = 464; // >= 16 * 28, = 16 mod 32
+// ... and 21 .. 32 tiles (GW): the tiles beyond the 160 accumulator slots wait in the U pool, at their own place
+constexpr int POTRF_REG8W_MAXT = 32;
+constexpr int POTRF_REG8W_LDP = 528; // >= 16 * 32, = 16 mod 32
 constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13, = 16 mod 32
 // ------------------------------------------------------------------------------------------------
 // k_potrf_reg<SLOTS>: the same factorisation for units whose whole upper triangle of 16x16 tiles fits on
@@ -1188,11 +1188,11 @@ constexpr int POTRF_REG2_LDP = 240;  // the two-per-CU instantiation: >= 16 * 13
 // at once) becomes arithmetic spread over the launch; k_mgrad<.,.,false> re-evaluates the values it needs.
 // Every wave has 256 registers (20 tile slots = a[0:159] + 96 VGPRs).  RW = 4: units of up to 13 tiles per edge, TWO
 // workgroups per CU — a unit's factorisation is a latency chain that keeps its SIMDs a quarter busy, so two of them side by
-// side nearly double the CU's throughput; RW = 8: one workgroup per CU, units of up to 20 (GW: 28) tiles.  Units outside
+// side nearly double the CU's throughput; RW = 8: one workgroup per CU, units of up to 20 (GW: 32) tiles.  Units outside
 // [min_T, reg_maxT] are left alone.  (Rounds 1-4 also had a four-wave form with 512 registers per wave, a run-ahead step
 // loop without workgroup barriers and ("lld","matern32") generation in here: each measured slower than what is left —
 // DESIGN.md section 4 — and removed in round 5.)
-// GW (eight-wave instantiation, K from the pool): units of up to 28 tiles per edge — the (up to 218) tiles beyond the
+// GW (eight-wave instantiation, K from the pool): units of up to 32 tiles per edge — the (up to 336) tiles beyond the
 // accumulator slots wait in GLOBAL memory instead of LDS: in the U pool, each at its own final place (nobody else touches a
 // tile of U before its row is solved), read and written through the CU's L1 / the L2 like the generic kernel's whole trailing
 // matrix — a fraction of that kernel's traffic (the first rows only, and only until they retire).  Waves of one workgroup
@@ -1898,7 +1898,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k
                                                                                            int reg_maxT, KParams kp, int which) {
     potrf_reg_body<8, SLOTS, GEN>(ut, pl, stamps, reg_maxT, kp, which);
 }
-// ... units of 21 .. 28 tiles per edge (and, in a launch that has such units, every smaller one too), K from the pool: the
+// ... units of 21 .. 32 tiles per edge (and, in a launch that has such units, every smaller one too), K from the pool: the
 // tiles beyond the accumulator slots wait in the U pool (GW)
 template <int SLOTS>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(96))) void k_potrf_reg8w(UnitTab ut, Pools pl, int stamps,
@@ -3838,7 +3838,7 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 //   fused_build=0   table build + coordinate scatter as three launches      gx_fold=0     k_gx_finalize as a launch of its own
 //   one_queue=1     both Cholesky instantiations on the main queue          side_events=1 fork / join of the two queues by events
 //   part_major=0/1  solve / gradient grids unit by unit / part by part      potrf_reg=0   every unit through the generic Cholesky
-//   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-28 tiles on the generic kernel
+//   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-32 tiles on the generic kernel
 //   pipe=<percent>  solve / At / gradient as two pipelines (off)            max_unit=<points>  a lower GPRF_MAX_UNIT (refusal-path tests)
 //   potrf_stamps=1..3  which wave's cycle stamps a -DGPRF_PROFILE build records    grid_hint=0  k_assign scans every centre
 //   big_super=<n>   block rows of 64 per super-block of the blocked path (read once per process)
@@ -4556,7 +4556,7 @@ constexpr int POTRF_SMALL_MAXT = 13;
 // Cholesky.)  k_mgrad re-evaluates the values it needs in both cases.
 // diag potrf_reg=0: every unit through the generic kernel (tests: the register kernels against it, bit for bit)
 static bool potrf_use_reg() { return diag("potrf_reg", 1) != 0; }
-// units of 21 .. 28 tiles per edge on the eight-wave kernel with its waiting tiles in the U pool (diag potrf_gw=0: the generic
+// units of 21 .. 32 tiles per edge on the eight-wave kernel with its waiting tiles in the U pool (diag potrf_gw=0: the generic
 // kernel)
 static bool potrf_gw() { return diag("potrf_gw", 1) != 0; }
 bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
@@ -4566,12 +4566,12 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut) {
     // and is gone since round 5)
     const bool se = dist_id == 0 && kern_id == 0;
     // a launch with units of more than 20 tiles per edge goes through the K pool as a whole: ONE eight-wave kernel then takes
-    // every unit of up to 28 tiles (waiting tiles in the U pool) — behind the generating kernels it would run by itself, a
+    // every unit of up to 32 tiles (waiting tiles in the U pool) — behind the generating kernels it would run by itself, a
     // unit's whole chain later (measured, 49 blocks of ~184 points + 156 pairs of 20-27 tiles: fill + Cholesky 32 + 281 us
     // against 28 + 439)
     // — when such units are MANY (an eighth of the launch, at least 16).  A few (one pair of a north-star-shaped partition
     // growing past 320 points) leave the others generated, as round 2 decided per unit: they are filled, and take the
-    // eight-wave kernel (up to 28 tiles) or the generic one behind the generating kernels.
+    // eight-wave kernel (up to 32 tiles) or the generic one behind the generating kernels.
     if (ut.max_T > 20 && potrf_gw() && ut.n_wide >= 16 && 8 * ut.n_wide >= ut.n_ids) return false;
     return diag("fused_fill", 1) != 0 && se && ut.n_ids > 0 && potrf_use_reg();
 }
@@ -4654,7 +4654,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     // units of more than reg_maxT tiles per edge: the generic kernel, from the K pool (its workgroups leave the others alone)
     auto launch_generic = [&]() {
         if (ut.max_T <= reg_maxT) return;
-        // the few units of 21 .. 28 tiles per edge of a generating launch: the eight-wave kernel with its waiting tiles in the
+        // the few units of 21 .. 32 tiles per edge of a generating launch: the eight-wave kernel with its waiting tiles in the
         // U pool, from the K pool (they were filled), behind the generating kernels; the generic kernel above that
         if (gen && potrf_gw() && reg_maxT == POTRF_REG8_MAXT) {
             launch_reg8w(dim3(ut.n_ids), s, ut, p, stamps, kp, POTRF_REG8_MAXT + 1);
