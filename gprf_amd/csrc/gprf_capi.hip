@@ -131,6 +131,7 @@ struct gprf_ctx {
     DevBuf<SlotRec> d_srec, d_big_rec, d_small_rec;
     int grid_big = 0, grid_small = 0;     // launch sizes of the Cholesky's two lists (list lengths at the last sync + slack)
     int n_wide = 0;                       // local units of more than 20 tiles per edge at the last sync (potrf_generates_K)
+    int n_la_big = 0, n_la_small = 0;     // ... of more than / at most BIG_LA_T tiles (the blocked path's / the one-workgroup kernels')
     View<double> d_weight, d_jitter;
     DevBuf<char> d_tab;
     PinBuf<char> h_tab;
@@ -330,6 +331,8 @@ void refresh_host_units(gprf_ctx *c) {
         nwide += pad16(c->l_m[l]) / 16 > 20 ? 1 : 0;      // units the generating Cholesky kernels do not take
     }
     c->n_wide = nwide;
+    c->n_la_big = c->n_la_small = 0;
+    for (int l = 0; l < nl; ++l) (pad16(c->l_m[l]) / 16 > BIG_LA_T ? c->n_la_big : c->n_la_small)++;
     // (surplus workgroups of the large-unit launch take small units, see potrf_reg_body: slack costs nothing there; the
     // small-unit launch simply covers every unit)
     if (nbig + 8 > c->grid_big || nbig + 96 < c->grid_big) c->grid_big = std::min(nl, nbig + 32);
@@ -701,6 +704,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     mark();
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
+    bool beside = false;      // the blocked path's Cholesky / substitution beside the small units' (below)
     launch_fill(c->dist_id, c->kern_id, ut, pl, kp, gen ? potrf_gen_maxT(c->dist_id) : 0, s);
     mark();
     if (stop_after >= 1) {
@@ -708,8 +712,22 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         side.s2 = c->stream2; side.ev_fork = c->ev_fork; side.ev_join = c->ev_join;
         side.words = c->side_values ? c->d_side.p : nullptr;
         side.seq = ++c->side_seq;
+        // A launch with units on BOTH sides of BIG_LA_T (the reference's 25- / 36-block partitions: unaries of 280-400 points,
+        // pairs of 560-870): the blocked path's launches run BESIDE the one-workgroup-per-unit kernels, on the third queue —
+        // independent units, and neither side fills the chip alone (the few units of 21-32 tiles live 300-400 us on their CUs
+        // while the blocked path issues its ~40 us steps)
+        beside = c->n_la_big > 0 && c->n_la_small > 0 && ut.max_T > BIG_LA_T && c->stream3 && c->side_values && s == c->stream &&
+                 !potrf_tool_env() && !tm && diag("big_beside", 1) != 0;
+        uint32_t *w = c->d_side.p;
+        if (beside) {
+            HIP_TRY(c, hipStreamWriteValue32(s, w + 6, side.seq, 0));      // (the fill is done)
+            HIP_TRY(c, hipStreamWaitValue32(c->stream3, w + 6, side.seq, hipStreamWaitValueGte, 0xffffffffu));
+            launch_big_potrf(ut, pl, kp, c->stream3);
+            HIP_TRY(c, hipStreamWriteValue32(c->stream3, w + 7, side.seq, 0));
+        }
         launch_potrf(ut, pl, kp, gen, s, side);
-        launch_big_potrf(ut, pl, kp, s);
+        if (beside) HIP_TRY(c, hipStreamWaitValue32(s, w + 7, side.seq, hipStreamWaitValueGte, 0xffffffffu));
+        else launch_big_potrf(ut, pl, kp, s);
     }
     mark();
     // ---- round 5, measured and left OFF: the three GEMM-shaped stages as TWO pipelines side by side (GPRF_DIAG pipe=<percent>) ----
@@ -750,8 +768,19 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         mark(); mark();
     } else {
     if (stop_after >= 2) {
-        launch_solve(ut, pl, kp, s);
-        launch_big_solve(ut, pl, s);
+        if (beside) {
+            uint32_t *w = c->d_side.p;
+            const uint32_t seq = c->side_seq;
+            HIP_TRY(c, hipStreamWriteValue32(s, w + 8, seq, 0));      // (both Cholesky sides are done: the join above)
+            HIP_TRY(c, hipStreamWaitValue32(c->stream3, w + 8, seq, hipStreamWaitValueGte, 0xffffffffu));
+            launch_big_solve(ut, pl, c->stream3);
+            HIP_TRY(c, hipStreamWriteValue32(c->stream3, w + 9, seq, 0));
+            launch_solve(ut, pl, kp, s);
+            HIP_TRY(c, hipStreamWaitValue32(s, w + 9, seq, hipStreamWaitValueGte, 0xffffffffu));
+        } else {
+            launch_solve(ut, pl, kp, s);
+            launch_big_solve(ut, pl, s);
+        }
     }
     mark();
     if (stop_after >= 3) launch_at(ut, pl, s);

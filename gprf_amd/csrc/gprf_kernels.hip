@@ -3841,7 +3841,8 @@ static int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * npar
 //   fused_fill=0    K always through the pool (k_fill)                      potrf_gw=0    units of 21-32 tiles on the generic kernel
 //   pipe=<percent>  solve / At / gradient as two pipelines (off)            max_unit=<points>  a lower GPRF_MAX_UNIT (refusal-path tests)
 //   potrf_stamps=1..3  which wave's cycle stamps a -DGPRF_PROFILE build records    grid_hint=0  k_assign scans every centre
-//   big_super=<n>   block rows of 64 per super-block of the blocked path (read once per process)
+//   big_super=<n>   block rows of 64 per super-block of the blocked path (read once per process); big_super_solve=<n>: the sweep's
+//   big_beside=0    the blocked path's Cholesky / substitution behind the one-workgroup kernels instead of beside them (mixed launches)
 // Read at every call (a handful of string searches per evaluation): a test may change it between two contexts of one process.
 int diag(const char *key, int dflt) {
     const char *e = getenv("GPRF_DIAG");
