@@ -4735,11 +4735,10 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
 }
 
 void launch_solve(const UnitTab &ut_all, const Pools &p, const KParams &kp, hipStream_t s) {
-    const UnitTab &ut = ut_all;
-    if (ut.n_ids == 0) return;
+    if (ut_all.n_ids == 0) return;
     // PM: the grid walked part by part (part_major_map) — launches at most two rounds of CUs wide; diag part_major=0 / 1 forces
     const int pm_d = diag("part_major", -1);
-    const bool pm = pm_d >= 0 ? pm_d == 1 : ut.n_ids <= 2 * device_cus();
+    const bool pm = pm_d >= 0 ? pm_d == 1 : ut_all.n_ids <= 2 * device_cus();
     // (GPRF_ONLY_POTRF: tests/test_isa_invariants.py compiles this file for the Cholesky kernels' ISA alone — the dozen
     // unrolled k_solve_panel / k_mgrad instantiations are two thirds of the compile time)
 #ifndef GPRF_ONLY_POTRF
