@@ -637,10 +637,13 @@ def main():
     # the blocked multi-launch path (k_big_*); gprf_results.tgz has the reference's own seconds per evaluation beside them
     if n_members == 1 and not args.only_north_star and args.ntrain == 10000:
         big = {}
-        for nbk, ld, tag, ref_s in ((9, 0.1, "9 blocks + 20 pairs", 85.33), (1, 1.0, "1 block (full GP)", 233.55)):
+        # (round 5: + the 25- and 49-block partitions — pairs of ~800 / ~450 points, whose Cholesky and substitution moved to the
+        # blocked path / the 32-tile register kernel)
+        for nbk, ld, tag, ref_s in ((49, 0.1, "49 blocks + 156 pairs", 13.3), (25, 0.1, "25 blocks + 72 pairs", 27.6),
+                                    (9, 0.1, "9 blocks + 20 pairs", 85.33), (1, 1.0, "1 block (full GP)", 233.55)):
             sd.set_centers(grid_centers(nbk))
             gb = sd.build_gprf(local_dist=ld, device=local_rank)
-            rate, ms, smp = sequential_rate(gb, Xlist[:3], 3 if nbk == 9 else 2, 1, grad_cov, 1)
+            rate, ms, smp = sequential_rate(gb, Xlist[:3], 6 if nbk > 9 else (3 if nbk == 9 else 2), 1, grad_cov, 1)
             szb = gdist.unit_sizes(sd.block_idxs, sd.neighbors if ld < 1.0 else [])
             big[tag] = {"evals_per_s": rate, "ms_per_eval": ms, "largest_unit_points": int(szb.max()),
                         "algorithmic_TFLOPs": algorithmic_flops(szb, args.yd)["total"] * rate / 1e12,
