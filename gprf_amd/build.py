@@ -6,8 +6,32 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # GPRF_LIB: diagnostic builds (ablation / profile variants) live next to the product library under another name
 LIB = os.environ.get("GPRF_LIB") or os.path.join(HERE, "libgprf_hip.so")
-SOURCES = ["gprf_kernels.hip", "gprf_capi.hip"]
-HEADERS = ["gprf_kernels.h", os.path.join("..", "..", "include", "gprf_hip.h")]
+# one translation unit per stage (round 6: the 5000-line kernel file compiled 2 m 46 s as one unit; split, the files compile
+# side by side and a kernel variant recompiles one of them)
+# (slowest first: they start first)
+SOURCES = ["gprf_solve_wide32.hip", "gprf_solve_wide.hip", "gprf_solve.hip", "gprf_potrf.hip", "gprf_mgrad.hip", "gprf_big.hip",
+           "gprf_fill.hip", "gprf_tables.hip", "gprf_capi.hip"]
+HEADERS = ["gprf_kernels.h", "gprf_dev.h", "gprf_solve_panel.h", os.path.join("..", "..", "include", "gprf_hip.h")]
+
+
+def source_hash():
+    """sha256 over the native sources and headers (sorted by name): a committed rocprofv3 counter figure counts for THIS code
+    only if it was taken on the same sources — the GPU box has no git to ask (bench.py, scripts/prof_summary.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _flag_tag():
+    """what LIB was built WITH, besides its sources: the define / flag set (GPRF_BUILD_DEFS).  Stored next to the library
+    (LIB + ".tag"), so that `GPRF_BUILD_DEFS=-DGPRF_PROFILE python gprf_amd/build.py` rebuilds a library that is up to date by
+    its mtimes but was compiled with other defines — and the next plain build restores the product library."""
+    import hashlib
+    return hashlib.sha256(" ".join(_flags()).encode()).hexdigest()[:16]
 
 
 def _stale():
@@ -15,7 +39,13 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:
+        with open(LIB + ".tag") as f:
+            return f.read().strip() != _flag_tag()
+    except OSError:
+        return False        # (a library without a tag file: built before round 6, or shipped alone — trusted by its mtimes)
 
 
 def have_compiler():
@@ -72,23 +102,35 @@ def _build_locked(verbose, force=False):
         path = os.path.join(objdir, old)
         if old.endswith(".o") and ("." + tag + ".") not in old and time.time() - os.path.getmtime(path) > 7 * 86400:
             os.remove(path)
-    objs = []
+    objs, jobs = [], []
     for f in SOURCES:
         src = os.path.join(CSRC, f)
         obj = os.path.join(objdir, "%s.%s.o" % (os.path.splitext(f)[0], tag))
-        # (>=: a header touched within the same clock tick as the object counts as newer)
+        # (strictly newer: a header touched within the same clock tick as the object counts as changed)
         if force or not (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t)):
-            cmd = [hipcc] + flags + ["-c", "-o", obj + ".tmp.%d" % os.getpid(), src]
-            if verbose:
-                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-                print(" ".join(cmd))
-            try:
-                subprocess.check_call(cmd)
-                os.replace(obj + ".tmp.%d" % os.getpid(), obj)
-            finally:
-                if os.path.exists(obj + ".tmp.%d" % os.getpid()):
-                    os.remove(obj + ".tmp.%d" % os.getpid())
+            jobs.append((src, obj))
         objs.append(obj)
+
+    def compile_one(job):
+        src, obj = job
+        tmp_o = obj + ".tmp.%d" % os.getpid()
+        cmd = [hipcc] + flags + ["-c", "-o", tmp_o, src]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp_o, obj)
+        finally:
+            if os.path.exists(tmp_o):
+                os.remove(tmp_o)
+
+    if jobs:
+        # the files side by side (hipcc is one process per file; GPRF_BUILD_JOBS bounds them, default: the cores, at most 8)
+        from concurrent.futures import ThreadPoolExecutor
+        nj = max(1, min(len(jobs), int(os.environ.get("GPRF_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)))
+        with ThreadPoolExecutor(nj) as ex:
+            list(ex.map(compile_one, jobs))
     tmp = "%s.tmp.%d" % (LIB, os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-pthread",
            "-Wl,--no-undefined",      # a symbol one source file declares and the other forgot to define fails HERE
@@ -96,6 +138,8 @@ def _build_locked(verbose, force=False):
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, LIB)
+        with open(LIB + ".tag", "w") as f:
+            f.write(_flag_tag() + "\n")
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)

@@ -1,4 +1,4 @@
-// gprf_kernels.h — shared declarations between the HIP kernels (gprf_kernels.hip) and the C-ABI host
+// gprf_kernels.h — shared declarations between the HIP kernels (gprf_<stage>.hip, device helpers in gprf_dev.h) and the C-ABI host
 // layer (gprf_capi.hip).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -203,7 +203,7 @@ bool potrf_generates_K(int dist_id, int kern_id, const UnitTab &ut);
 int potrf_gen_maxT(int dist_id);   // (20)
 int potrf_small_maxT();         // the register-resident Cholesky runs as two instantiations side by side: units of at most this
                                 // many tiles per edge two to a CU
-int diag(const char *key, int dflt);   // GPRF_DIAG="key=value,...": the one diagnostic switch (gprf_kernels.hip)
+int diag(const char *key, int dflt);   // GPRF_DIAG="key=value,...": the one diagnostic switch (gprf_tables.hip)
 int potrf_side_mode();          // how the two queues fork / join (launch_potrf): 4 = kernel-written fork word + memory-op join, 0 = events
 bool potrf_tool_env();          // a profiler / serialising launch mode is in the environment
 // The second queue for the instantiation that runs beside the main one, and how the two queues wait for each other:

@@ -240,6 +240,50 @@ class GPRF(object):
         """gprf.py:176-179"""
         self.X[self.block_idxs[i]] = new_X
 
+    def subset_llgrad(self, blocks):
+        """gprf.py:182-204: the objective over a SUBSET of the blocks — their unaries and only the pairs between members
+        of the subset, Bethe weights from the neighbour counts INSIDE the subset.  Returns the log-likelihood alone, as the
+        reference does.  One library evaluation: the blocks outside the subset are installed empty (an empty unit
+        contributes exactly 0, gprf.py:507-513) and the in-set pairs are the neighbour list, from which the library
+        derives the local counts; the object's own partition and neighbour list are re-installed by the next call that
+        needs them.  A block listed k times counts k times, as in the reference's list comprehension."""
+        if self._shard[1] > 1 and self._reduce:
+            raise NotImplementedError("subset_llgrad on a sharded GPRF: evaluate it on one rank (the reference never calls it)")
+        blocks = [int(b) for b in blocks]
+        block_set = set(blocks)
+        neighbors_in_set = [(i, j) for (i, j) in self.neighbors if i in block_set and j in block_set]
+        full = self.block_idxs                   # (runs a pending re-blocking, like reading the attribute anywhere else)
+        empty = np.zeros(0, dtype=np.int64)
+        X = np.ascontiguousarray(self.X, dtype=np.float64)
+
+        def evaluate(members, nbrs):
+            ptr, pts = _csr_from_block_idxs([full[b] if b in members else empty for b in range(self.n_blocks)])
+            self._ctx.set_blocks(ptr, pts)
+            self._ctx.set_neighbors(nbrs)
+            self._ctx.set_unit_jitter(None)
+            self._blocks_pushed, self._nbrs_pushed, self._jitter = None, nbrs, None
+            rc, ll, _, _, bad = self._ctx.eval(X, False, False)
+            if rc == _capi.GPRF_NOT_PD:
+                rc, ll, _, _ = self._retry_with_jitter(X, False, False, bad)
+            return ll
+
+        try:
+            ll = evaluate(block_set, neighbors_in_set)
+            counts = defaultdict(int)
+            for (i, j) in neighbors_in_set:
+                counts[i] += 1
+                counts[j] += 1
+            seen = set()
+            for b in blocks:                     # a repeated block: its weighted unary once more per repetition
+                if b in seen:
+                    ll += (1 - counts[b]) * evaluate({b}, [])
+                seen.add(b)
+        finally:
+            # the library holds the subset now: the next llgrad / objective call re-installs the object's own state
+            self._blocks_pushed, self._nbrs_pushed, self._jitter = None, None, None
+            self._ctx.set_unit_jitter(None)
+        return ll
+
     def llgrad(self, parallel=False, local=True, grad_X=False, grad_cov=False, **kwargs):
         """gprf.py:206-296 -> (ll, gradX (n,dx) or (0,0), gradCov (1,ncov) or (0,0)).
 

@@ -98,6 +98,20 @@ class GPRFRef(object):
         if recompute_neighbors:
             self.compute_neighbors(threshold=self.neighbor_threshold)
 
+    # -- gprf.py:182-204
+    def subset_llgrad(self, blocks):
+        block_set = set(blocks)
+        neighbors_in_set = [(i, j) for (i, j) in self.neighbors if i in block_set and j in block_set]
+        local_neighbor_counts = defaultdict(int)
+        for (i, j) in neighbors_in_set:
+            local_neighbor_counts[i] += 1
+            local_neighbor_counts[j] += 1
+        unary_lls = [self.llgrad_unary(i, grad_X=False, grad_cov=False)[0] for i in blocks]
+        pair_lls = [self.llgrad_joint(i, j, grad_X=False, grad_cov=False)[0] for (i, j) in neighbors_in_set]
+        ll = np.sum(pair_lls)
+        ll += np.sum([(1 - local_neighbor_counts[blocks[i]]) * ull for (i, ull) in enumerate(unary_lls)])
+        return ll
+
     # -- gprf.py:206-296 (serial branch)
     def llgrad(self, parallel=False, local=True, **kwargs):
         if local:

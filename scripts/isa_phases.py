@@ -1,5 +1,5 @@
 """Instruction histogram of one kernel's ISA, split at its s_barrier's:
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_kernels.hip
+   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_<stage>.hip   (potrf | solve | mgrad | big | fill | tables)
    python scripts/isa_phases.py k.s k_potrf_reg"""
 import sys
 

@@ -1,5 +1,5 @@
 """Per-kernel register / LDS / scratch use from the compiler's metadata:
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_kernels.hip
+   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_<stage>.hip   (potrf | solve | mgrad | big | fill | tables)
    python scripts/isa_resources.py k.s [name filter]"""
 import re, sys
 

@@ -1,7 +1,7 @@
 """Exposed memory round trips in the compiled kernels: every `s_waitcnt vmcnt(0)` (or lgkmcnt(0) behind an s_load) that sits
 between two vector-memory loads is a full memory latency that nothing overlaps.  Per kernel: loads, stores, vmcnt(0) waits, and
 the longest run of load -> vmcnt(0) -> load -> vmcnt(0) ... without anything else in flight.
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_kernels.hip
+   hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o k.s gprf_amd/csrc/gprf_<stage>.hip   (potrf | solve | mgrad | big | fill | tables)
    python scripts/isa_serial_loads.py k.s [name filter]"""
 import re, sys
 

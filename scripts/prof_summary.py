@@ -81,11 +81,9 @@ for nm in sorted(vals):
                    "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
     print("%-14s grid %8d  FETCH_SIZE %10.0f KiB  WRITE_SIZE %10.0f KiB  -> %.1f MB" % (nm, g, fetch_kib, write_kib, traffic[nm]["bytes_per_launch"] / 1e6))
 # the native sources these counters belong to (bench.py reports the traffic only for exactly these)
-import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for f in ("gprf_amd/csrc/gprf_kernels.hip", "gprf_amd/csrc/gprf_capi.hip", "gprf_amd/csrc/gprf_kernels.h", "include/gprf_hip.h"):
-    h.update(open(os.path.join(root, f), "rb").read())
-traffic["source_hash"] = h.hexdigest()[:16]
+sys.path.insert(0, root)
+from gprf_amd import build as hip_build
+traffic["source_hash"] = hip_build.source_hash()
 with open(os.path.join(out, "traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1, sort_keys=True)

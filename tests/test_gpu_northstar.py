@@ -7,7 +7,7 @@ lscale=0.06, obs_std=0.02, with and without the 342 neighbour pairs.  Checks
     on the assembled 342-pair gradient, away from an 80-bit evaluation; max |gradX| ~ 2e5), so what is asserted is (i)
     closeness to the 80-BIT TRUTH relative to the oracle's own (|GPU - true| <= 0.85 |oracle - true| assembled, 1.15 local; per pair
     unit: pooled maximum, mean ratio and worst ratio, 40 units) and (ii) a bound on |GPU - oracle|, two fp64 paths:
-    4e-8 (local GP) / 3e-7 (342 pairs); ll relative 1e-12; gC relative 1e-9 (DESIGN.md section 5);
+    3.1e-8 (local GP) / 1.55e-7 (342 pairs) = measured + 15 %; ll relative 1e-12; gC relative 1e-9 (DESIGN.md section 5);
   * size-independent properties: directional finite difference, Bethe sum rule.
 Inputs are regenerated from seeds on the GPU box (N=10500 prior Cholesky through torch on the GPU)."""
 import numpy as np
@@ -55,7 +55,7 @@ def _oracle(sdata, local_dist):
 # (Numerics).  Two independent fp64 evaluations therefore cannot agree to 1e-8 here.  What is
 # required instead: (a) the GPU is as close to the TRUE gradient as the reference path is (asserted below on
 # the full gradient and, unit by unit, on pair units: <= 1.5x the oracle's own error), and (b) GPU and oracle agree
-# to twice the difference measured in round 1 (4e-8 local, 3e-7 with the 8-neighbourhood), i.e. to within their
+# to the difference measured in round 5 plus 15 % (3.1e-8 local, 1.55e-7 with the 8-neighbourhood), i.e. to within their
 # common rounding floor with no room for a regression.
 
 
@@ -106,9 +106,9 @@ def test_gradient_against_oracle_and_extended_precision(sdata, local_dist):
     # and the ABSOLUTE errors are pinned too, so that the trade made in round 4 stays the trade it was
     assert e_gt <= (1.15 if local_dist == 1.0 else 0.85) * e_ot
     assert e_gt <= (2.2e-8 if local_dist == 1.0 else 9.5e-8)
-    # (b) agreement at the common rounding floor: at most TWICE what round 1 measured on MI355X (1.94e-8 without /
-    # 1.52e-7 with the 342 pair units: profiles/r01_final_pytest_gpu.log) — a 2x regression fails
-    assert e_go <= (4e-8 if local_dist == 1.0 else 3e-7)
+    # (b) agreement at the common rounding floor: the values measured on MI355X in round 5 (2.63e-8 without / 1.33e-7 with the
+    # 342 pair units: profiles/r05_numerics.log) plus 15 % — rounds 1-5 allowed 4e-8 / 3e-7, 1.5-2.3x the measurement
+    assert e_go <= (3.1e-8 if local_dist == 1.0 else 1.55e-7)
     assert np.isclose(ll, o_ll, rtol=1e-12)
     assert abs(float(ll - t_ll)) <= 1e-12 * abs(float(t_ll))
     assert np.allclose(gC, o_gC, rtol=1e-9)

@@ -109,6 +109,8 @@ sz = [len(u) for u in g.block_idxs]
 tiles = sorted(set((sz[i] + sz[j] + 15) // 16 for i, j in g.neighbors))
 if n == 2400:
     assert tiles[0] >= 17 and 19 in tiles and 20 in tiles and tiles[-1] > 20, tiles
+elif n == 3900:
+    assert 31 in tiles and 32 in tiles and tiles[0] >= 26, tiles
 else:
     assert tiles[0] >= 21 and tiles[-1] > 28 and len([t for t in tiles if 21 <= t <= 28]) >= 5, tiles
 ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
@@ -139,11 +141,11 @@ def test_units_of_17_to_20_tiles_on_the_eight_wave_cholesky(tmp_path):
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
 
 
-def test_units_of_21_to_28_tiles_wait_in_the_U_pool(tmp_path):
+def test_units_of_21_to_32_tiles_wait_in_the_U_pool(tmp_path):
     """16 blocks of ~206 points: pairs of 24-30 tiles per edge.  A launch with units above 20 tiles goes through the K pool as a
-    whole and ONE eight-wave register kernel takes every unit of up to 28 tiles, the tiles beyond its 160 accumulator slots
-    waiting in the U pool (in place, through L2); the 29- and 30-tile pairs take the generic kernel.  GPRF_DIAG potrf_gw=0: the
-    generating kernels for units of up to 20 tiles, the generic kernel above — the same bits"""
+    whole and ONE eight-wave register kernel takes every unit of up to 32 tiles (28 until round 5), the tiles beyond its 160
+    accumulator slots waiting in the U pool (in place, through L2).  GPRF_DIAG potrf_gw=0: the generating kernels for units of
+    up to 20 tiles, the generic kernel above — the same bits.  (31- and 32-tile units: the next test.)"""
     import numpy as np
     (tmp_path / "wide.py").write_text(WIDE_DRIVER)
     out = {}
@@ -159,6 +161,38 @@ def test_units_of_21_to_28_tiles_wait_in_the_U_pool(tmp_path):
     for tag in ("pool", "generic", "pool generic", "all generic"):
         b = out[tag]
         assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
+
+
+def test_units_of_31_and_32_tiles_against_the_generic_kernel(tmp_path):
+    """16 blocks of ~244 points: pairs of 26-34 tiles per edge, among them 31 and 32 (496 .. 512 points: the last sizes the
+    eight-wave kernel takes, up to 336 tiles waiting in the U pool, 141 KB of LDS), the larger ones on the blocked path beside
+    them.  Against potrf_gw=0 (generic kernel above 20 tiles) and potrf_reg=0 (generic kernel for everything): the same bits"""
+    import numpy as np
+    (tmp_path / "wide.py").write_text(WIDE_DRIVER)
+    out = {}
+    for tag, env in (("gw", {}), ("generic", {"GPRF_DIAG": "potrf_gw=0"}), ("all generic", {"GPRF_DIAG": "potrf_reg=0"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), WIDE_N="3900")
+        e.update(env)
+        r = subprocess.run([sys.executable, str(tmp_path / "wide.py"), str(tmp_path / (tag.replace(" ", "_") + ".npz"))], cwd=str(tmp_path),
+                           env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        out[tag] = np.load(str(tmp_path / (tag.replace(" ", "_") + ".npz")))
+    a = out["gw"]
+    for tag in ("generic", "all generic"):
+        b = out[tag]
+        assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"]), tag
+
+
+def test_blocked_path_beside_the_one_workgroup_kernels_bit_for_bit(tmp_path):
+    """A launch with units on BOTH sides of the one-workgroup limit (25 blocks of ~400 points = 25 tiles: the eight-wave
+    kernel; their 72 pairs of ~800 points: the blocked path): by default the blocked Cholesky / substitution run BESIDE the
+    one-workgroup kernels on a third queue, joined by stream memory operations.  Against one after the other
+    (big_beside=0), and that with one Cholesky queue: a cross-queue race would show as different bits on a walk of six
+    re-partitioned evaluations"""
+    shape = {"VAR_N": "10000", "VAR_BLOCKS": "25"}
+    base = run_variant(tmp_path, shape)
+    for d in ("big_beside=0", "one_queue=1,big_beside=0"):
+        assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
 FEW_WIDE_DRIVER = r'''

@@ -9,23 +9,29 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gprf_amd", "csrc", "gprf_kernels.hip")
+SRC = os.path.join(ROOT, "gprf_amd", "csrc", "gprf_potrf.hip")      # the Cholesky kernels' own translation unit
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _compile(tmp_path_factory, src):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / (os.path.basename(src) + ".s"))
+    # (the same source file and flags as the shipped object: gprf_amd/build.py)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",       # as gprf_amd/build.py
+                           "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
 
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
-    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
-        pytest.skip("hipcc not available")
-    out = str(tmp_path_factory.mktemp("isa") / "gprf_kernels.s")
-    # (-DGPRF_ONLY_POTRF: the Cholesky kernels alone — the unrolled k_solve_panel / k_mgrad instantiations are two thirds of
-    # the file's compile time and nothing here looks at them.  The macro only leaves the OTHER kernels' launch code out: a
-    # kernel's device code is generated per function and does not depend on which other kernels the translation unit holds, so
-    # the ISA checked here is the shipped object's)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DGPRF_ONLY_POTRF",
-                           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",       # as gprf_amd/build.py
-                           "-o", out, SRC], stderr=subprocess.DEVNULL)
-    return open(out).read().split("\n")
+    return _compile(tmp_path_factory, SRC)
+
+
+@pytest.fixture(scope="module")
+def isa_big(tmp_path_factory):
+    return _compile(tmp_path_factory, os.path.join(ROOT, "gprf_amd", "csrc", "gprf_big.hip"))      # the blocked path's kernels
 
 
 def _function(lines, mangled_part):
@@ -94,13 +100,13 @@ def _longest_exposed_run(body):
     return best
 
 
-def test_blocked_path_gemm_keeps_its_loads_in_flight(isa):
+def test_blocked_path_gemm_keeps_its_loads_in_flight(isa_big):
     """Round 5: k_big_gemm's operand fetch (a select around every load) and its epilogue (element-wise C -= acc) had compiled to
     load / s_waitcnt vmcnt(0) / load chains — 65 exposed round trips in a row, 39.9 ms instead of 33.6 for the 10000-point
     unit.  The branch-free fetch and the batched epilogue must stay that way: a handful of waits, and
     the chunk loop's prefetch outstanding across its barrier (a counted vmcnt, not 0)."""
-    body = _function(isa, "10k_big_gemmENS")
+    body = _function(isa_big, "10k_big_gemmENS")
     assert _longest_exposed_run(body) <= 8
     assert any(re.search(r"s_waitcnt vmcnt\((8|9|1\d)\)", l) for l in body)      # eight loads stay in flight behind the wait
     assert not [l for l in body if "scratch_" in l]
-    assert _longest_exposed_run(_function(isa, "12k_big_updateENS")) <= 2
+    assert _longest_exposed_run(_function(isa_big, "12k_big_updateENS")) <= 2

@@ -69,3 +69,20 @@ def test_rows_mode_equals_matrix_mode(sdata2000):
     rb = b.llgrad_joint(i, j, grad_X=True, grad_cov=True)
     assert ra[0] == rb[0]
     assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+
+
+def test_subset_llgrad_of_every_block_is_the_published_objective(sdata2000, published):
+    """gprf.py:182-204 restated: over ALL blocks the subset objective is the full objective, i.e. the published step-0 value
+    once the location prior is added; over one block it is that block's unary term (no pairs inside a singleton)."""
+    sd = sdata2000
+    sd.set_centers(grid_centers(9))
+    g = sd.build_gprf(local_dist=0.1)
+    assert len(g.neighbors) == 20
+    full = g.llgrad()[0]
+    assert np.isclose(g.subset_llgrad(list(range(9))), full, rtol=1e-13)
+    rec = published["2000_2500_9_0.134164_0.044721_0.1000_50_l-bfgs-b_x_-1_0.0100_s0_gprf0"]
+    assert "%.2f" % (g.subset_llgrad(list(range(9))) + sd.x_prior(sd.X_obs.flatten())[0]) == rec["steps"][0]["objective"]
+    assert g.subset_llgrad([4]) == g.llgrad_unary(4)[0]
+    # two neighbouring blocks: their pair minus nothing (each has ONE neighbour inside the subset: weight 1 - 1 = 0)
+    i, j = g.neighbors[0]
+    assert np.isclose(g.subset_llgrad([i, j]), g.llgrad_joint(i, j)[0], rtol=1e-13)
