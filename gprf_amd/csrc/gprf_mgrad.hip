@@ -821,7 +821,8 @@ void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, co
     const int pm = diag("part_major", 1) != 0 ? 1 : 0;
     // (round 5: the lld / Matern instantiation always in groups — its block pairs re-read W / At at 482 MB per launch walked
     // launch-wide on the seismic shape — and never with fewer than two groups: part_major_map then walks launch-wide)
-    const int G = (ut.n_launch > 2 * device_cus() || (dist_id == 1 && ut.n_launch > 128)) ? 64 : 0;      // (n_launch: see launch_solve)
+    const int G_d = diag("mgrad_group", -1);      // (diagnostic: the walk's group size, a multiple of 8; 0 = launch-wide)
+    const int G = G_d >= 0 ? G_d : ((ut.n_launch > 2 * device_cus() || (dist_id == 1 && ut.n_launch > 128)) ? 64 : 0);      // (n_launch: see launch_solve)
     const int nbp = TBm * (TBm + 1) / 2;
     dim3 grid(pm && G > 0 ? ((ut.n_ids + G - 1) / G) * G * nbp : xcd_grid(ut.n_ids, nbp));
     UnitTab utp = ut;

@@ -1178,6 +1178,9 @@ static void launch_reg8(dim3 grid, size_t lds, hipStream_t s, const UnitTab &ut,
 // a tool is labelled with the launch structure it shows.
 bool potrf_tool_env() {
     static const bool tool_env = [] {
+        // (diag tool_env=0: a tool is loaded but known not to serialise the queues — rocprofv3 --kernel-trace without counters:
+        // the trace then shows the product's own launch structure, scripts/profile_run.sh)
+        if (diag("tool_env", -1) == 0) return false;
         for (const char *v : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "AMD_SERIALIZE_KERNEL",
                               "HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION", "GPRF_SIDE_EVENTS"}) {
             const char *e = getenv(v);

@@ -40,6 +40,39 @@ for f in find("trace", "*kernel_stats.csv"):
             print("%-12s calls %6s  total_ns %12s  avg_ns %10s  min %8s max %8s  pct %s" % (
                 nm, r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("MinNs"), r.get("MaxNs"), r.get("Percentage")))
 
+# The kernel-trace pass runs the PRODUCT's launch structure (GPRF_DIAG=tool_env=0: two Cholesky queues forked by the kernel-written
+# word and joined by a stream memory operation — rocprofv3 --kernel-trace without counters does not serialise the queues): the
+# Cholesky STAGE is the span from the first of its kernels' start to the last one's end, per evaluation, from the trace's own
+# timestamps; likewise the whole evaluation (k_assign / k_route start -> k_done end).
+import statistics
+for f in find("trace", "*kernel_trace.csv"):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    evals, cur = [], None
+    for r in rows:
+        n = short(r.get("Kernel_Name", ""))
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if n in ("k_assign", "k_route"):
+            if cur: evals.append(cur)
+            cur = {"t0": s_, "potrf": [], "end": None, "q": set()}
+        elif cur is not None:
+            if n.startswith("k_potrf_reg"):
+                cur["potrf"].append((s_, e_))
+                cur["q"].add(r.get("Queue_Id"))
+            elif n in ("k_done", "k_finish"):
+                cur["end"] = e_
+    if cur: evals.append(cur)
+    two = [c for c in evals if len(c["potrf"]) == 2 and c["end"]]
+    if two:
+        span = [(max(e for _, e in c["potrf"]) - min(s for s, _ in c["potrf"])) / 1e3 for c in two]
+        ovl = [(min(e for _, e in c["potrf"]) - max(s for s, _ in c["potrf"])) / 1e3 for c in two]
+        whole = [(c["end"] - c["t0"]) / 1e3 for c in two]
+        print("== stage spans from the kernel trace (product launch structure: %d evaluations with both Cholesky kernels, on %d queues) ==" % (
+            len(two), max(len(c["q"]) for c in two)))
+        print("Cholesky stage (first kernel start -> last kernel end): median %.1f us  min %.1f  max %.1f ; the two kernels overlap %.1f us (median)" % (
+            statistics.median(span), min(span), max(span), statistics.median(ovl)))
+        print("whole evaluation on the device (k_assign start -> k_done end): median %.1f us  min %.1f  max %.1f" % (
+            statistics.median(whole), min(whole), max(whole)))
+
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     files = find(sub, "*counter_collection.csv")
     if not files:

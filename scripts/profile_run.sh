@@ -7,7 +7,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 CMD="python3 bench.py --only-north-star --steps 100 --warmup 10"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
+# (the trace pass shows the PRODUCT's launch structure: without counters rocprofv3 does not serialise the queues, and
+# GPRF_DIAG=tool_env=0 keeps the library from switching to events / one queue because a tool is loaded; bounded all the same)
+GPRF_DIAG=tool_env=0 GPRF_EVAL_TIMEOUT_S=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
 # counter passes: the profiler serialises the dispatches of ALL queues, and a stream-memory-operation wait in front of
 # the solve (the join of the two Cholesky queues) then never sees its value written — the library puts the two Cholesky
 # kernels on one queue when it sees ROCPROF_COUNTER_COLLECTION (set by --pmc); every pass under `timeout` all the same
@@ -19,5 +21,5 @@ python3 scripts/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || true
 # keep the merge-back small: the per-dispatch CSVs of the PMC passes are large
 find $OUT -name "*counter_collection.csv" -size +8M -delete
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
 cat $OUT/summary.txt | head -60
