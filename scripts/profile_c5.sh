@@ -14,6 +14,6 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
 python3 scripts/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*counter_collection.csv" -size +8M -delete
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
 cat $OUT/trace.log | tail -5
 cat $OUT/summary.txt | head -70

@@ -44,5 +44,5 @@ if k and avg_ns:
     print("fill counters:", d)
 PY
 find $OUT -name "*counter_collection.csv" -size +8M -delete
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
 grep "k_fill\|== k_fill" -A12 $OUT/summary.txt | head -60
