@@ -622,12 +622,6 @@ def main():
             "host_gap_ms": round(ms_per_step - kernels_ms, 5) if n_members == 1 else None,
         }
 
-    # ---------------- parity figures of THIS run (outside the timed region): a sample of the timed configuration's units, the
-    # device's per-unit log-likelihood and gradient rows against the oracle's on the same inputs (the oracle is the checker
-    # here, nothing else), plus the assembled objective / gradient of the sub-problem made of exactly those units
-    if rank == 0 and n_members == 1 and not args.no_parity:
-        result["parity"] = parity_sample(g, sd, Xlist[0], nbrs, grad_cov)
-
     # ---------------- secondary figures
     if not args.only_north_star:
         # blocks fixed (no update_X): the llgrad-only rate of SURVEY 8d
@@ -664,6 +658,9 @@ def main():
         # write rate is measured on the side by forcing the K pool back for a few evaluations
         # (gprf_debug_run with stop_after = 0: gather + the fill of EVERY unit, nothing else)
         e = evs[0]
+        for _ in range(2):      # (the K pool's allocation and first touch are not the kernel's time)
+            e.g._ctx.debug_run(Xlist[0], 0)
+        torch.cuda.synchronize()
         e.g._ctx.set_timing(True, reset=True)
         for _ in range(8):
             e.g._ctx.debug_run(Xlist[0], 0)
@@ -816,6 +813,18 @@ def main():
                                         "algorithmic_TFLOPs": fl6["total"] * c6 / 1e12}
         g6.close()
         del g6, X6, Y6, X6s
+
+    # ---------------- parity figures of THIS run: a sample of the timed configuration's units, the device's per-unit
+    # log-likelihood and gradient rows against the oracle's on the same inputs (the oracle is the checker here, nothing else).
+    # Behind every timed leg, on a context of its own, and with ONE BLAS thread: a LAPACK thread pool left spinning on the
+    # cores this process is pinned to would disturb whatever is timed after it
+    if rank == 0 and n_members == 1 and not args.no_parity:
+        from threadpoolctl import threadpool_limits
+        sd.set_centers(grid_centers(args.nblocks))
+        gp = sd.build_gprf(local_dist=args.local_dist, device=local_rank)
+        with threadpool_limits(limits=1):
+            result["parity"] = parity_sample(gp, sd, Xlist[0], nbrs, grad_cov)
+        gp.close()
 
     if n_members == 1 and not args.only_north_star and not args.no_cpu_baseline:
         if affinity_before is not None:

@@ -6,7 +6,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python3 bench.py --only-north-star --steps 100 --warmup 10"
+CMD="python3 bench.py --only-north-star --no-parity --steps 100 --warmup 10"
 # (the trace pass shows the PRODUCT's launch structure: without counters rocprofv3 does not serialise the queues, and
 # GPRF_DIAG=tool_env=0 keeps the library from switching to events / one queue because a tool is loaded; bounded all the same)
 GPRF_DIAG=tool_env=0 GPRF_EVAL_TIMEOUT_S=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
