@@ -611,7 +611,10 @@ def main():
                                       "units sharded over %d rank(s), 1 all-reduce/eval" % world,
                        "host": ("process pinned to the GPU's NUMA node %d (%d cpus)" % (numa_node, numa_cpus)) if numa_node >= 0
                                else "CPU affinity left as found",
-                       "group": group_info, "library": _capi.runtime_config()},
+                       "group": group_info, "library": _capi.runtime_config(),
+                       "strong_scaling_note": "the 442 units of this configuration are ONE round of workgroups on one GPU and its floor at any N is one "
+                                              "16-tile unit's chain through four stages: c4_evals_per_s (n=80000, 4033 units) is the "
+                                              "configuration whose work shards (DESIGN.md section 7)"},
             "roofline": roof,
             **({"note": "GPRF_BENCH_ONE_GPU=1 test run: all ranks / members time-share one GPU; not a measurement"} if one_gpu else {}),
             "stages_ms": {k2: round(v, 5) for k2, v in stage.items()},
