@@ -621,9 +621,29 @@ def main():
             "kernels_ms_per_eval": round(kernels_ms, 5),
             "stage_timing": "separate pass behind the timed region: %d sequential evaluations with HIP events between the kernels "
                             "of every one (%.4f ms per evaluation with the events; the headline has none); 'gather' includes "
-                            "the re-partition and table-build kernels" % (cnt, ms_with_events),
-            "host_gap_ms": round(ms_per_step - kernels_ms, 5) if n_members == 1 else None,
+                            "the re-partition and table-build kernels.  With its timers on the library runs the stages LAUNCH-WIDE, one "
+                            "kernel after the other: these are per-kernel durations (the roofline's).  The timed region itself "
+                            "pipelines the two size classes' Cholesky -> substitution -> At -> gradient on two queues "
+                            "(config.library class_depth; DESIGN.md section 4.7), so ms_per_step is SHORTER than the stages' sum; "
+                            "'launch_wide' is the same loop with that pipelining off" % (cnt, ms_with_events),
+            "host_gap_ms": None,      # (meaningful only where the stages run one after the other: launch_wide.host_gap_ms)
         }
+        # the same timed loop with the by-class pipelining off (GPRF_DIAG solve_class=0): what the stage times above add up to
+        if n_members == 1:
+            prev = os.environ.get("GPRF_DIAG")
+            os.environ["GPRF_DIAG"] = (prev + "," if prev else "") + "solve_class=0"
+            try:
+                lw_value, lw_ms, lw_samples = sequential_rate(g, Xlist, args.steps, args.warmup, grad_cov, 3)
+            finally:
+                if prev is None:
+                    os.environ.pop("GPRF_DIAG", None)
+                else:
+                    os.environ["GPRF_DIAG"] = prev
+            result["launch_wide"] = {"value": lw_value, "ms_per_step": lw_ms, "ms_per_step_samples": [round(v, 5) for v in lw_samples],
+                                     "host_gap_ms": round(lw_ms - kernels_ms, 5),
+                                     "note": "GPRF_DIAG=solve_class=0: every stage one launch over all units, the queues joined behind the "
+                                             "Cholesky (rounds 1-5); bit-identical results (tests/test_gpu_variants.py)"}
+            result["pipelining_gain"] = lw_ms / ms_per_step
 
     # ---------------- secondary figures
     if not args.only_north_star:

@@ -705,6 +705,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
     // (the K pool exists only when somebody reads it: a fill-only debug run, the generic Cholesky, big units)
     bool gen = stop_after >= 1 && potrf_generates_K(c->dist_id, c->kern_id, ut);
     bool beside = false;      // the blocked path's Cholesky / substitution beside the small units' (below)
+    int solved = 0;           // stages behind the Cholesky that launch_potrf ran itself (by size class, on its two queues): 1 solve, 2 + At, 3 + gradient
     launch_fill(c->dist_id, c->kern_id, ut, pl, kp, gen ? potrf_gen_maxT(c->dist_id) : 0, s);
     mark();
     if (stop_after >= 1) {
@@ -725,7 +726,15 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
             launch_big_potrf(ut, pl, kp, c->stream3);
             HIP_TRY(c, hipStreamWriteValue32(c->stream3, w + 7, side.seq, 0));
         }
-        launch_potrf(ut, pl, kp, gen, s, side);
+        // (round 6: a two-queue launch runs each size class's substitution, At and gradient behind that class's Cholesky kernel on
+        // its queue and joins the queues behind them — the plain launch-wide structure only: not beside the blocked path, not
+        // under the split pipelines, and not under the per-stage timers, which time one launch-wide stage after the other)
+        // (... and on the library's own stream: ten contexts enqueued back to back on ONE caller's stream — bench.py's
+        // device-resident figure — share a few hardware queues between their side streams, and four more kernels on each
+        // cost that form 12 %)
+        const bool plain = !beside && !tm && s == c->stream && !(diag("pipe", PIPE_DEFAULT_PCT) > 0 && diag("pipe", PIPE_DEFAULT_PCT) < 100);
+        const int want_stages = !plain ? 0 : (do_grad ? 3 : (stop_after >= 3 ? 2 : (stop_after >= 2 ? 1 : 0)));
+        solved = launch_potrf(ut, pl, kp, gen, s, side, want_stages, want_gc);
         if (beside) HIP_TRY(c, hipStreamWaitValue32(s, w + 7, side.seq, hipStreamWaitValueGte, 0xffffffffu));
         else launch_big_potrf(ut, pl, kp, s);
     }
@@ -778,14 +787,14 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
             launch_solve(ut, pl, kp, s);
             HIP_TRY(c, hipStreamWaitValue32(s, w + 9, seq, hipStreamWaitValueGte, 0xffffffffu));
         } else {
-            launch_solve(ut, pl, kp, s);
+            if (solved < 1) launch_solve(ut, pl, kp, s);
             launch_big_solve(ut, pl, s);
         }
     }
     mark();
-    if (stop_after >= 3) launch_at(ut, pl, s);
+    if (stop_after >= 3 && solved < 2) launch_at(ut, pl, s);
     mark();
-    if (do_grad) launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
+    if (do_grad && solved < 3) launch_grad(c->dist_id, c->kern_id, ut, pl, kp, want_gc, !gen, s);      // (re-evaluates k whenever K was generated for some units)
     }
     if (do_grad) {
         // k_gx_finalize is a launch of its own for sums the assembly can do on the way (10 us of a 430 us evaluation) —
@@ -1327,7 +1336,8 @@ int gprf_group_info(const gprf_ctx *c, int32_t *n_members, int32_t *slots_on_hos
 const char *gprf_runtime_config(void) {
     static thread_local char buf[256];
     const char *io = getenv("GPRF_IO_MODE"), *sy = getenv("GPRF_SYNC"), *dg = getenv("GPRF_DIAG");
-    snprintf(buf, sizeof buf, "side_mode=%d tool_env=%d io_mode=%d sync=%s diag=%.120s", potrf_side_mode(), potrf_tool_env() ? 1 : 0,
+    snprintf(buf, sizeof buf, "side_mode=%d tool_env=%d class_depth=%d io_mode=%d sync=%s diag=%.120s", potrf_side_mode(), potrf_tool_env() ? 1 : 0,
+             diag("solve_class", 1) != 0 ? diag("class_depth", 3) : 0,
              (io && (io[0] == '1' || io[0] == '2')) ? io[0] - '0' : 0, (sy && sy[0] == 'b') ? "block" : "poll", dg ? dg : "");
     return buf;
 }

@@ -89,6 +89,31 @@ __device__ __forceinline__ UnitRef unit_ref(const SlotRec *__restrict__ rec, int
     return x;
 }
 
+// The Cholesky's two size classes as launch lists of their own (round 6).  The tables are built on the device with the
+// partition: big_rec / small_rec hold the units of more than / at most potrf_small_maxT() tiles in launch order, their
+// lengths are ctl[CTL_NBIG] / ctl[CTL_NSMALL]; the large-unit Cholesky kernel's surplus workgroups (grid_big beyond its list)
+// take units from the END of the small list.  CLS 1 = the large list + those surplus units (everything the main queue's
+// Cholesky kernel factors), CLS 2 = the rest of the small list (the side queue's), CLS 0 = the whole launch order.
+struct ClassList { int n, nb, ns; };
+template <int CLS>
+__device__ __forceinline__ ClassList class_list(const UnitTab &ut) {
+    ClassList c{ut.n_ids, 0, 0};
+    if constexpr (CLS != 0) {
+        c.nb = ut.ctl[CTL_NBIG];
+        c.ns = ut.ctl[CTL_NSMALL];
+        int surplus = ut.grid_big > c.nb ? ut.grid_big - c.nb : 0;
+        if (surplus > c.ns) surplus = c.ns;
+        c.n = CLS == 1 ? c.nb + surplus : c.ns - surplus;
+    }
+    return c;
+}
+template <int CLS>
+__device__ __forceinline__ UnitRef class_unit(const UnitTab &ut, const ClassList &c, int slot) {
+    if constexpr (CLS == 0) return unit_ref(ut.srec, slot);
+    else if constexpr (CLS == 2) return unit_ref(ut.small_rec, slot);
+    else return slot < c.nb ? unit_ref(ut.big_rec, slot) : unit_ref(ut.small_rec, c.ns - 1 - (slot - c.nb));
+}
+
 // Diagnostic builds (-DGPRF_WGTRACE=<id>: 1 solve, 2 at, 3 mgrad, 4 / 5 the Cholesky's 512- / 256-register kernel): every workgroup of that kernel records when and where
 // it ran — (start, end) of the constant-rate counter, the HW_ID / XCC_ID registers — for scripts/gpu_wg_trace.py.
 struct WgTrace {

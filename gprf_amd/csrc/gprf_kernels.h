@@ -216,8 +216,18 @@ struct SideQueue {
     uint32_t seq = 0;               // value of this evaluation (monotonic)
 };
 // gen: the register kernels generate K themselves (SE)
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side);
+// class_stages: how many of the stages behind the Cholesky the caller wants next (1 solve, 2 + At, 3 + gradient) — a two-queue
+// launch then runs each size class's stages behind that class's Cholesky kernel on its queue and joins the queues behind
+// them (round 6); returns how many it ran (the caller skips those launches)
+int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side, int class_stages,
+                 int want_gc);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
+// the forward substitution of ONE of the Cholesky's two size classes (which = 1: the large units + the surplus units of the
+// small list; 2: the small list), and whether a launch is split that way (diag solve_class=0: never)
+void launch_solve_class(const UnitTab &ut, const Pools &p, int dy, int which, hipStream_t s);
+void launch_at_class(const UnitTab &ut, const Pools &p, int which, hipStream_t s);
+void launch_grad_class(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, int which, hipStream_t s);
+bool solve_by_class(const UnitTab &ut);
 // units of more than 1024 points: blocked Cholesky and forward substitution over whole launches (no-ops when the launch has none)
 void launch_big_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 void launch_big_solve(const UnitTab &ut, const Pools &p, hipStream_t s);

@@ -44,7 +44,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // BIG (round 5): the units of more than 1024 points only — their M tiles were made by k_big_gemm (mode 2, 128 x 128 tiles at
 // four times this kernel's flops per byte) and wait in the unit's region of the K pool: the chunk loop is skipped, the
 // accumulators are loaded, the reductions are the same code.  The plain instantiations leave those units alone.
-template <int DIST, int KERN, bool HAVEK, int FAST, bool BIG = false>
+template <int DIST, int KERN, bool HAVEK, int FAST, bool BIG = false, int CLS = 0>
 #ifndef GPRF_MGRAD_LLD_WPC
 #define GPRF_MGRAD_LLD_WPC 2
 #endif
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : GP
     __shared__ double xsh[128 * PtRec<DIST>::NREG];
     int TBm = (ut.max_T + 3) >> 2;
     int slot, bp;
+    ClassList cl{ut.n_ids, 0, 0};
     WgTrace trace(ut, pl, 3);
     // (part_major: every unit's block pair 0 first, then every unit's pair 1, ...: pairs are in order of descending length)
     if constexpr (BIG) {
@@ -67,8 +68,13 @@ __global__ __launch_bounds__(256, (DIST == 0 && KERN == 0) ? (FAST ? 4 : 3) : GP
         bp = (int)blockIdx.x - slot * nbp;
         if (slot >= ut.n_ids) return;
     } else
-    if (!(part_major ? part_major_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, ut.pm_group, &slot, &bp) : xcd_map(blockIdx.x, ut.n_ids, TBm * (TBm + 1) / 2, &slot, &bp))) return;
-    const UnitRef ur = unit_ref(ut.srec, slot);
+    {
+        cl = class_list<CLS>(ut);
+        if (cl.n <= 0) return;
+        if (!(part_major ? part_major_map(blockIdx.x, cl.n, TBm * (TBm + 1) / 2, ut.pm_group, &slot, &bp) : xcd_map(blockIdx.x, cl.n, TBm * (TBm + 1) / 2, &slot, &bp))) return;
+        if (CLS != 0 && bp >= TBm * (TBm + 1) / 2) return;      // (a grid sized for more units than the partition has)
+    }
+    const UnitRef ur = BIG ? unit_ref(ut.srec, slot) : class_unit<CLS>(ut, cl, slot);
     int u = ur.u;
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
@@ -808,6 +814,24 @@ void launch_finish(double *out, const ObjTab &ob, int nparts, double xp_const, d
 void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, hipStream_t s) {
     if (ut.n_units == 0) return;
     hipLaunchKernelGGL(k_gx_finalize, dim3(ut.n_units), dim3(256), 0, s, ut, p, kp, want_gc);
+}
+
+// the gradient kernel of one size class (SE kernel, at most two input dimensions: the configurations launch_potrf pipelines by
+// class), behind that class's At on its queue; launch-wide part-major walk over the class's list
+void launch_grad_class(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, int which, hipStream_t s) {
+    const int TBm = (ut.max_T + 3) / 4, nbp = TBm * (TBm + 1) / 2;
+    UnitTab utp = ut;
+    utp.pm_group = 0;
+    const int n = which == 1 ? ut.grid_big : ut.grid_small;
+    if (n <= 0) return;
+    dim3 grid(xcd_grid(n, nbp));
+    if (which == 1) {
+        if (want_gc) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2, false, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
+        else hipLaunchKernelGGL((k_mgrad<0, 0, false, 1, false, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
+    } else {
+        if (want_gc) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2, false, 2>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
+        else hipLaunchKernelGGL((k_mgrad<0, 0, false, 1, false, 2>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
+    }
 }
 
 void launch_grad(int dist_id, int kern_id, const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc,

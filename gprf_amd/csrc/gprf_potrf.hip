@@ -1205,8 +1205,9 @@ static bool potrf_one_queue() {
     return counters || diag("one_queue", 0) != 0;
 }
 
-void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side) {
-    if (ut.n_ids == 0) return;
+int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side, int class_stages,
+                 int want_gc) {
+    if (ut.n_ids == 0) return 0;
     hipStream_t s2 = side.s2;
     const int stamps = diag("potrf_stamps", 0);      // diagnostic builds (-DGPRF_PROFILE): in-kernel cycle stamps into Pools::dbg
     // every unit of up to 20 tiles per edge on the register-resident kernels (28 with its waiting tiles in the U pool), the
@@ -1233,7 +1234,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     };
     if (!reg_maxT) {
         launch_generic();
-        return;
+        return 0;
     }
     const int capT = ut.max_T < reg_maxT ? ut.max_T : reg_maxT;
     if (!gen) {
@@ -1246,12 +1247,12 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         } else
             launch_reg8(dim3(ut.n_ids), potrf_reg8_lds(capT, 0) * sizeof(double), s, ut, p, stamps, reg_maxT, kp, 0, false);
         launch_generic();
-        return;
+        return 0;
     }
     if (ut.max_T <= POTRF_SMALL_MAXT) {      // every unit has at most 13 tiles: the two-per-CU kernel alone
         size_t ldsS = (size_t)(16 * POTRF_REG2_LDP + 256 + 16 + 256 + 16 * POTRF_REG_MAXT_C + 256 * capT + 16 * capT * XPAD) * sizeof(double);
         launch_reg2(dim3(ut.n_ids), ldsS, s, ut, p, stamps, POTRF_SMALL_MAXT, kp, 0);
-        return;
+        return 0;
     }
     // two instantiations side by side on two queues: units of up to 13 tiles per edge two to a CU, the larger ones one to a
     // CU; each over its own device-built list (an early-exit workgroup of the eight-wave kernel still needs an EMPTY CU to
@@ -1273,8 +1274,24 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
     }
     // (the large-unit kernel must go FIRST and on the main queue: launched behind the two-per-CU kernel it waits for whole
     // CUs to drain — measured: stage 178-264 us instead of 121)
+    // round 6: each class's forward substitution behind its own Cholesky kernel, on that kernel's queue; the join below then
+    // waits for both (nothing else of this launch may be left for the generic kernel: max_T <= 16)
+    // (how deep: diag class_depth=<1..3>; the gradient kernel by class exists for the SE kernel's two-dimensional instantiations)
+    int depth = (s2 != s && solve_by_class(ut)) ? class_stages : 0;
+    {
+        // (a launch more than two rounds of CUs deep — C4: 4033 units — keeps its gradient kernel launch-wide: that kernel
+        // walks such launches in groups of 64 slots for its L2 residency, and by class it measured 2.60-2.64 ms per evaluation
+        // against 2.55-2.56 with the first two stages alone and 2.64-2.72 with none)
+        const int cap = diag("class_depth", ut.n_launch <= 2 * device_cus() ? 3 : 2);
+        if (depth > cap) depth = cap;
+        if (depth > 2 && kp.dx > 2) depth = 2;
+    }
+    const bool by_class = depth >= 1;
     if (ut.grid_big > 0)
         launch_reg8(dim3(ut.grid_big), potrf_reg8_lds(capT, XPAD) * sizeof(double), s, utb, p, stamps, reg_maxT, kp, 1, true);
+    if (by_class) launch_solve_class(ut, p, kp.dy, 1, s);
+    if (depth >= 2) launch_at_class(ut, p, 1, s);
+    if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 1, s);
     if (fork_kernel) {
         // (should that launch ever be refused, nothing would write the word the side queue waits for)
         if (hipPeekAtLastError() != hipSuccess) (void)hipStreamWriteValue32(s, side.words + 2, side.seq, 0);
@@ -1285,6 +1302,9 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
     }
     if (ut.grid_small > 0) launch_reg2(dim3(ut.grid_small), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
+    if (by_class) launch_solve_class(ut, p, kp.dy, 2, s2);
+    if (depth >= 2) launch_at_class(ut, p, 2, s2);
+    if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 2, s2);
     if (s2 != s) {      // join
         if (values) {
             (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);
@@ -1295,6 +1315,7 @@ void launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen
         }
     }
     launch_generic();
+    return depth;
 }
 
 }  // namespace gprf

@@ -10,16 +10,20 @@ namespace gprf {
 // the snake gives 34 each) and all four 16-row blocks of At for each (16 accumulators).  The k-loop runs
 // DOWN from the last row tile so the four waves need the same Z chunk at the same time (shared through L1):
 // per k-tile 16 Z operands are loaded once and reused for up to four column tiles.
+template <int CLS = 0>
 __global__ __launch_bounds__(256, 2) void k_at_wide(UnitTab ut, Pools pl, int first_round, int skip_T) {
     int slot_, part_;
     WgTrace trace(ut, pl, 2);
-    if (!xcd_map(blockIdx.x, ut.n_ids, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    const ClassList cl = class_list<CLS>(ut);
+    if (cl.n <= 0) return;
+    if (!xcd_map(blockIdx.x, cl.n, (ut.max_T + 15) >> 4, &slot_, &part_)) return;
+    if (CLS != 0 && part_ >= ((ut.max_T + 15) >> 4)) return;
     // A launch of at most two workgroups per CU is resident all at once: workgroup first_round + j (first_round = the CUs)
     // becomes the second resident of the CU that took workgroup j.  The launch order is largest unit first, so the CU of the
     // largest unit also got the largest of the rest, and the launch lasted as long as those two sharing four SIMDs; with the
     // second round in ASCENDING size the largest unit is paired with the smallest.
-    if (first_round > 0 && slot_ >= first_round) slot_ = ut.n_ids - 1 - (slot_ - first_round);
-    const UnitRef ur = unit_ref(ut.srec, slot_);
+    if (first_round > 0 && slot_ >= first_round) slot_ = cl.n - 1 - (slot_ - first_round);
+    const UnitRef ur = class_unit<CLS>(ut, cl, slot_);
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;
     int I0 = 16 * part_;
@@ -156,6 +160,44 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl, int skip_T)
 }
 
 
+// The substitution by size class (round 6).  In-kernel records of where the stage's time goes (-DGPRF_WGTRACE=1): the launch is
+// ~3 rounds of workgroups of which the FIRST — every unit's Y workgroup and first identity workgroup, all full T-step chains
+// starting together — lasts 50 of the 76 us at three workgroups per CU, their waves waiting for panels and updating in step with
+// each other; the 16-tile instantiation's 128 accumulator registers are what holds the CU at three.  352 of the north-star's
+// 442 units have at most 13 tiles: k_solve_panel<13, 4> fits 128 registers and 30 KB of LDS — FOUR workgroups per CU — and
+// the Cholesky already runs as two kernels over exactly these two classes on two queues: each class's substitution goes
+// behind its own Cholesky kernel, on that queue, and the queues join behind the substitutions instead of in front.
+constexpr int SOLVE_CLASS_MAXT = 16;      // the large class's instantiation (launches whose largest unit has more tiles: one launch)
+bool solve_by_class(const UnitTab &ut) {
+    return diag("solve_class", 1) != 0 && potrf_small_maxT() == 13 && ut.max_T > potrf_small_maxT() && ut.max_T <= SOLVE_CLASS_MAXT;
+}
+// ... and At of one class behind its substitution (k_at_wide over the class's list; the large class is fewer workgroups than
+// CUs, the small one a single round of two per CU)
+void launch_at_class(const UnitTab &ut, const Pools &p, int which, hipStream_t s) {
+    const int parts = (ut.max_T + 15) / 16;
+    if (which == 1) {
+        if (ut.grid_big > 0) hipLaunchKernelGGL(k_at_wide<1>, dim3(xcd_grid(ut.grid_big, parts)), dim3(256), 0, s, ut, p, 0, MAX_T);
+    } else {
+        if (ut.grid_small > 0) hipLaunchKernelGGL(k_at_wide<2>, dim3(xcd_grid(ut.grid_small, parts)), dim3(256), 0, s, ut, p, 0, MAX_T);
+    }
+}
+void launch_solve_class(const UnitTab &ut, const Pools &p, int dy, int which, hipStream_t s) {
+    UnitTab utp = ut;
+    utp.pm_group = 0;
+    if (which == 1) {
+        if (ut.grid_big <= 0) return;
+        utp.max_T = SOLVE_CLASS_MAXT;
+        const int nparts = (utp.max_T + 3) / 4 + 1;
+        // (the large list + at most grid_big - |large list| surplus units: never more than grid_big)
+        hipLaunchKernelGGL((k_solve_panel<SOLVE_CLASS_MAXT, 3, true, 1, 1>), dim3(xcd_grid(ut.grid_big, nparts)), dim3(256), 0, s, utp, p, dy);
+    } else {
+        if (ut.grid_small <= 0) return;
+        utp.max_T = 13;
+        const int nparts = (utp.max_T + 3) / 4 + 1;
+        hipLaunchKernelGGL((k_solve_panel<13, 4, true, 1, 2>), dim3(xcd_grid(ut.grid_small, nparts)), dim3(256), 0, s, utp, p, dy);
+    }
+}
+
 void launch_solve(const UnitTab &ut_all, const Pools &p, const KParams &kp, hipStream_t s) {
     if (ut_all.n_ids == 0) return;
     // PM: the grid walked part by part (part_major_map) — launches at most two rounds of CUs wide; diag part_major=0 / 1 forces
@@ -213,7 +255,7 @@ void launch_at(const UnitTab &ut, const Pools &p, hipStream_t s) {
     }
     // ONE round of at most two workgroups per CU: the second resident of a CU in ASCENDING size (largest with smallest)
     const int first_round = (ut.max_T <= 16 && ut.n_ids > cus && ut.n_ids <= 2 * cus) ? cus : 0;
-    hipLaunchKernelGGL(k_at_wide, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round, skip_T);
+    hipLaunchKernelGGL(k_at_wide<0>, dim3(xcd_grid(ut.n_ids, (ut.max_T + 15) / 16)), dim3(256), 0, s, ut, p, first_round, skip_T);
 }
 
 }  // namespace gprf

@@ -24,7 +24,12 @@ constexpr int SOLVE_PANEL_MAXT = 32;  // largest k_solve_panel instantiation (ac
 // NBUF = 1 (round 4, units of 21 .. 26 tiles): ONE panel buffer — 52 KB + V_rr instead of 104: TWO workgroups per CU where the
 // double-buffered form has one; the next panel is requested behind a second barrier (nobody reads the current one any more) and
 // its round trip is exposed to this workgroup — the other workgroup of the CU computes meanwhile
-template <int MAXT, int WPS, bool PM, int NBUF = 2>
+// CLS (round 6): 0 = the launch order (UnitTab::srec); 1 / 2 = one of the Cholesky's two device-built lists — the units of more
+// than / at most potrf_small_maxT() tiles — each behind ITS Cholesky kernel on that kernel's queue (launch_potrf), the small
+// class with an instantiation of its own size at four workgroups per CU.  The large-unit Cholesky's surplus workgroups take
+// units from the END of the small list (potrf_reg_body): those units are solved by class 1 too, behind the kernel that
+// factored them.
+template <int MAXT, int WPS, bool PM, int NBUF = 2, int CLS = 0>
 __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, int dy) {
     // panel columns are stored RELATIVE to the first column right of the diagonal tile (16(r+1)): a step loads and
     // keeps only what its updates read.  (LDP/16) odd: lane groups 32 banks apart
@@ -42,12 +47,17 @@ __global__ __launch_bounds__(256, WPS) void k_solve_panel(UnitTab ut, Pools pl, 
     // (PM instantiations: a negative group size selects the unit-major walk at run time — the large instantiations exist once,
     // their compile time is minutes; the small hot ones keep the walk a template parameter: as a run-time field the same
     // kernel was 5 % slower)
-    if (!(PM ? (ut.pm_group >= 0 ? part_major_map(blockIdx.x, ut.n_ids, nI + 1, ut.pm_group, &slot_, &part_)
-                                 : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))
-             : xcd_map(blockIdx.x, ut.n_ids, nI + 1, &slot_, &part_))) return;
+    // (CLS != 0: this class's units in THIS partition; the grid follows the last synchronised partition with slack)
+    const ClassList cl = class_list<CLS>(ut);
+    const int n_ids = cl.n;
+    if (n_ids <= 0) return;
+    if (!(PM ? (ut.pm_group >= 0 ? part_major_map(blockIdx.x, n_ids, nI + 1, ut.pm_group, &slot_, &part_)
+                                 : xcd_map(blockIdx.x, n_ids, nI + 1, &slot_, &part_))
+             : xcd_map(blockIdx.x, n_ids, nI + 1, &slot_, &part_))) return;
+    if (CLS != 0 && part_ > nI) return;          // (a grid sized for more units than the partition has)
     // the Y workgroup (every step, a gather in front) is the longest of a unit: it is dispatched first
     part_ = part_ == 0 ? nI : part_ - 1;
-    const UnitRef ur = unit_ref(ut.srec, slot_);
+    const UnitRef ur = class_unit<CLS>(ut, cl, slot_);
     int u = ur.u;
     int m = ur.m;
     int mp = pad16(m), T = mp >> 4;

@@ -77,7 +77,7 @@ def test_pipelined_stages_equal_launch_wide_stages_bit_for_bit(tmp_path):
     was measured no faster, profiles/r05_pipeline_ab.txt) and against it with one Cholesky queue and the unit-by-unit walk."""
     shape = {"VAR_N": "5000", "VAR_BLOCKS": "100"}
     base = run_variant(tmp_path, shape)
-    for d in ("pipe=50", "pipe=25", "pipe=75", "one_queue=1,part_major=0"):
+    for d in ("pipe=50", "pipe=25", "pipe=75", "one_queue=1,part_major=0", "solve_class=0", "class_depth=2"):
         assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
@@ -89,6 +89,11 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       ("fork / join of the two Cholesky queues by events", {"GPRF_DIAG": "side_events=1"}),
                       ("solve / gradient grids walked unit by unit", {"GPRF_DIAG": "part_major=0"}),
                       ("nearest centre by the full scan instead of the grid's 3 x 3", {"GPRF_DIAG": "grid_hint=0"}),
+                      # round 6: each size class's forward substitution behind its own Cholesky kernel on that kernel's queue (the
+                      # small class with a 13-tile instantiation at four workgroups per CU) against ONE launch behind the join
+                      ("the substitution as one launch", {"GPRF_DIAG": "solve_class=0"}),
+                      ("only the substitution by class", {"GPRF_DIAG": "class_depth=1"}),
+                      ("substitution and At by class", {"GPRF_DIAG": "class_depth=2"}),
                       ("all of these at once", {"GPRF_DIAG": "fused_build=0,gx_fold=0,one_queue=1,part_major=0"})):
         assert run_variant(tmp_path, env) == base, name
 
