@@ -9,7 +9,7 @@ LIB = os.environ.get("GPRF_LIB") or os.path.join(HERE, "libgprf_hip.so")
 # one translation unit per stage (round 6: the 5000-line kernel file compiled 2 m 46 s as one unit; split, the files compile
 # side by side and a kernel variant recompiles one of them)
 # (slowest first: they start first)
-SOURCES = ["gprf_solve_wide32.hip", "gprf_solve_wide.hip", "gprf_solve.hip", "gprf_potrf.hip", "gprf_mgrad.hip", "gprf_big.hip",
+SOURCES = ["gprf_solve_wide32.hip", "gprf_solve_wide.hip", "gprf_solve.hip", "gprf_solve_class.hip", "gprf_potrf.hip", "gprf_mgrad.hip", "gprf_big.hip",
            "gprf_fill.hip", "gprf_tables.hip", "gprf_capi.hip"]
 HEADERS = ["gprf_kernels.h", "gprf_dev.h", "gprf_solve_panel.h", os.path.join("..", "..", "include", "gprf_hip.h")]
 

@@ -1289,9 +1289,6 @@ int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen,
     const bool by_class = depth >= 1;
     if (ut.grid_big > 0)
         launch_reg8(dim3(ut.grid_big), potrf_reg8_lds(capT, XPAD) * sizeof(double), s, utb, p, stamps, reg_maxT, kp, 1, true);
-    if (by_class) launch_solve_class(ut, p, kp.dy, 1, s);
-    if (depth >= 2) launch_at_class(ut, p, 1, s);
-    if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 1, s);
     if (fork_kernel) {
         // (should that launch ever be refused, nothing would write the word the side queue waits for)
         if (hipPeekAtLastError() != hipSuccess) (void)hipStreamWriteValue32(s, side.words + 2, side.seq, 0);
@@ -1302,9 +1299,15 @@ int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen,
         (void)hipStreamWaitValue32(s2, side.words + 2, side.seq, hipStreamWaitValueGte, 0xffffffffu);
     }
     if (ut.grid_small > 0) launch_reg2(dim3(ut.grid_small), ldsS, s2, ut, p, stamps, POTRF_SMALL_MAXT, kp, 2);
+    // (BOTH Cholesky kernels are submitted before any later stage: a launch costs the host 3-5 us, and with the large class's
+    // three later kernels submitted in front of it the side queue's Cholesky started 25 us behind the main queue's —
+    // rocprofv3 kernel trace, scripts/trace_eval_timeline.py.  The small class is the longer pipeline: its stages go in first.)
     if (by_class) launch_solve_class(ut, p, kp.dy, 2, s2);
+    if (by_class) launch_solve_class(ut, p, kp.dy, 1, s);
     if (depth >= 2) launch_at_class(ut, p, 2, s2);
+    if (depth >= 2) launch_at_class(ut, p, 1, s);
     if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 2, s2);
+    if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 1, s);
     if (s2 != s) {      // join
         if (values) {
             (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);

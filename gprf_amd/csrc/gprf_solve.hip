@@ -160,17 +160,6 @@ __global__ __launch_bounds__(256, 2) void k_at(UnitTab ut, Pools pl, int skip_T)
 }
 
 
-// The substitution by size class (round 6).  In-kernel records of where the stage's time goes (-DGPRF_WGTRACE=1): the launch is
-// ~3 rounds of workgroups of which the FIRST — every unit's Y workgroup and first identity workgroup, all full T-step chains
-// starting together — lasts 50 of the 76 us at three workgroups per CU, their waves waiting for panels and updating in step with
-// each other; the 16-tile instantiation's 128 accumulator registers are what holds the CU at three.  352 of the north-star's
-// 442 units have at most 13 tiles: k_solve_panel<13, 4> fits 128 registers and 30 KB of LDS — FOUR workgroups per CU — and
-// the Cholesky already runs as two kernels over exactly these two classes on two queues: each class's substitution goes
-// behind its own Cholesky kernel, on that queue, and the queues join behind the substitutions instead of in front.
-constexpr int SOLVE_CLASS_MAXT = 16;      // the large class's instantiation (launches whose largest unit has more tiles: one launch)
-bool solve_by_class(const UnitTab &ut) {
-    return diag("solve_class", 1) != 0 && potrf_small_maxT() == 13 && ut.max_T > potrf_small_maxT() && ut.max_T <= SOLVE_CLASS_MAXT;
-}
 // ... and At of one class behind its substitution (k_at_wide over the class's list; the large class is fewer workgroups than
 // CUs, the small one a single round of two per CU)
 void launch_at_class(const UnitTab &ut, const Pools &p, int which, hipStream_t s) {
@@ -179,22 +168,6 @@ void launch_at_class(const UnitTab &ut, const Pools &p, int which, hipStream_t s
         if (ut.grid_big > 0) hipLaunchKernelGGL(k_at_wide<1>, dim3(xcd_grid(ut.grid_big, parts)), dim3(256), 0, s, ut, p, 0, MAX_T);
     } else {
         if (ut.grid_small > 0) hipLaunchKernelGGL(k_at_wide<2>, dim3(xcd_grid(ut.grid_small, parts)), dim3(256), 0, s, ut, p, 0, MAX_T);
-    }
-}
-void launch_solve_class(const UnitTab &ut, const Pools &p, int dy, int which, hipStream_t s) {
-    UnitTab utp = ut;
-    utp.pm_group = 0;
-    if (which == 1) {
-        if (ut.grid_big <= 0) return;
-        utp.max_T = SOLVE_CLASS_MAXT;
-        const int nparts = (utp.max_T + 3) / 4 + 1;
-        // (the large list + at most grid_big - |large list| surplus units: never more than grid_big)
-        hipLaunchKernelGGL((k_solve_panel<SOLVE_CLASS_MAXT, 3, true, 1, 1>), dim3(xcd_grid(ut.grid_big, nparts)), dim3(256), 0, s, utp, p, dy);
-    } else {
-        if (ut.grid_small <= 0) return;
-        utp.max_T = 13;
-        const int nparts = (utp.max_T + 3) / 4 + 1;
-        hipLaunchKernelGGL((k_solve_panel<13, 4, true, 1, 2>), dim3(xcd_grid(ut.grid_small, nparts)), dim3(256), 0, s, utp, p, dy);
     }
 }
 
@@ -216,6 +189,10 @@ void launch_solve(const UnitTab &ut_all, const Pools &p, const KParams &kp, hipS
         if (ut.max_T <= 12) {
             if (pm) hipLaunchKernelGGL((k_solve_panel<12, 3, true>), grid, dim3(256), 0, s, utp, p, kp.dy);
             else hipLaunchKernelGGL((k_solve_panel<12, 3, false>), grid, dim3(256), 0, s, ut, p, kp.dy);
+        } else if (ut.max_T <= 13 && pm) {
+            // (round 6: 13 tiles fit 128 registers and 30 KB of LDS — FOUR workgroups per CU; the by-class pipelines' small-class
+            // instantiation, here for a launch whose every unit is that small)
+            hipLaunchKernelGGL((k_solve_panel<13, 4, true, 1>), grid, dim3(256), 0, s, utp, p, kp.dy);
         } else if (ut.max_T <= 16) {
             // units of 13 .. 16 tiles: ONE panel buffer at THREE workgroups per CU (35 KB of LDS, 157 VGPRs) against the
             // double-buffered 18-tile instantiation's two — round 4, measured: C3 87 -> 79 us, C4 633 -> 596

@@ -12,7 +12,23 @@ def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
+def size_class(name):
+    """round 6: the kernels of the by-class pipelines carry their size class as the last template argument"""
+    import re
+    m = re.search(r"k_solve_panel<\d+, \d+, (?:true|false), \d+, (\d)>", name)
+    if m: return {"1": "[large]", "2": "[small]"}.get(m.group(1), "")
+    m = re.search(r"k_at_wide<(\d)>", name)
+    if m: return {"1": "[large]", "2": "[small]"}.get(m.group(1), "")
+    m = re.search(r"k_mgrad<\d, \d, (?:true|false), \d, (?:true|false), (\d)>", name)
+    if m: return {"1": "[large]", "2": "[small]"}.get(m.group(1), "")
+    return ""
+
+
 def short(name):
+    return short0(name) + size_class(name)
+
+
+def short0(name):
     # the two instantiations that differ by where K comes from (demangled or mangled spelling)
     if "k_potrf_reg2" in name:
         return "k_potrf_reg2_gen"

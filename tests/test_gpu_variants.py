@@ -81,6 +81,19 @@ def test_pipelined_stages_equal_launch_wide_stages_bit_for_bit(tmp_path):
         assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
+@pytest.mark.parametrize("n,blocks", [(3700, 36), (1600, 16), (2100, 16)])
+def test_stages_pipelined_by_size_class_equal_launch_wide_stages_bit_for_bit(tmp_path, n, blocks):
+    """Round 6: in a two-queue launch each size class's substitution, At and gradient follow that class's Cholesky kernel on its
+    queue (the small class's substitution as a 13-tile instantiation at four workgroups per CU; the large class's as the 16- or
+    the 20-tile one).  Shapes: 36 blocks with pairs of 11-15 tiles (the north star's mix), 16 blocks with pairs of 12-15, and
+    pairs of 15-19 (the 20-tile large-class instantiation).  solve_class=0 runs every stage as one launch behind the join;
+    class_depth=1 / 2 stop the pipelines after the substitution / after At: every result of the walk the same bits"""
+    shape = {"VAR_N": str(n), "VAR_BLOCKS": str(blocks)}
+    base = run_variant(tmp_path, shape)
+    for d in ("solve_class=0", "class_depth=1", "class_depth=2"):
+        assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
+
+
 def test_launch_variants_agree_bit_for_bit(tmp_path):
     base = run_variant(tmp_path, {})
     for name, env in (("three-launch table build", {"GPRF_DIAG": "fused_build=0"}),
