@@ -335,7 +335,10 @@ void refresh_host_units(gprf_ctx *c) {
     for (int l = 0; l < nl; ++l) (pad16(c->l_m[l]) / 16 > BIG_LA_T ? c->n_la_big : c->n_la_small)++;
     // (surplus workgroups of the large-unit launch take small units, see potrf_reg_body: slack costs nothing there; the
     // small-unit launch simply covers every unit)
-    if (nbig + 8 > c->grid_big || nbig + 96 < c->grid_big) c->grid_big = std::min(nl, nbig + 32);
+    // (round 6: slack 32 -> 16.  The surplus workgroups take the SMALLEST units of the small list, each alone on a CU of its
+    // own: measured on the north star with the by-class pipelines, evaluations/s at slack 8 / 32 / 64 / 100: 2846, 2837 / 2829,
+    // 2806 / 2784, 2783 / 2766; 16 keeps room for the list to grow between two synchronised partitions)
+    if (nbig + 4 > c->grid_big || nbig + 48 < c->grid_big) c->grid_big = std::min(nl, nbig + 16);
     c->grid_small = nl;
 }
 
