@@ -52,6 +52,7 @@ SIGNATURES = {
     "gprf_work_estimate": (ctypes.c_int, [_vp, _dp, _dp]),
     "gprf_table_builds": (ctypes.c_int, [_vp, _i32p]),
     "gprf_set_timing": (ctypes.c_int, [_vp, _i32]),
+    "gprf_set_stream_pipelines": (ctypes.c_int, [_vp, _i32]),
     "gprf_get_timing": (ctypes.c_int, [_vp, _i32, _dp]),
     "gprf_set_x_prior": (ctypes.c_int, [_vp, _dp, ctypes.c_double]),
     "gprf_set_hyper_param": (ctypes.c_int, [_vp, _i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
@@ -434,6 +435,10 @@ class Context(object):
         return d
 
     # ---- per-stage parity hooks (tests) ----
+    def set_stream_pipelines(self, on):
+        """the by-class pipelines on a caller's stream too (gprf_set_stream_pipelines): for one evaluation at a time"""
+        self._check(self.lib.gprf_set_stream_pipelines(self.h, 1 if on else 0), "gprf_set_stream_pipelines")
+
     def debug_run(self, X, stop_after=6):
         X = np.ascontiguousarray(X, dtype=np.float64)
         self._check(self.lib.gprf_debug_run(self.h, dptr(X), stop_after), "gprf_debug_run")

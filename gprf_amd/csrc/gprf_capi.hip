@@ -87,6 +87,7 @@ struct gprf_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<uint32_t> d_side;               // fork / join words of the side queue (stream memory operations)
     uint32_t side_seq = 0;
+    bool caller_pipelines = false;        // gprf_set_stream_pipelines: the by-class pipelines on a caller's stream too
     GridHint grid_hint = {0, 0.0, 0.0, 0.0, 0.0};      // the centres are a uniform g x g grid (gprf_set_centers): k_assign's fast path
     bool side_values = false;             // the device supports hipStreamWaitValue32
     std::string err;
@@ -735,7 +736,7 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         // (... and on the library's own stream: ten contexts enqueued back to back on ONE caller's stream — bench.py's
         // device-resident figure — share a few hardware queues between their side streams, and four more kernels on each
         // cost that form 12 %)
-        const bool plain = !beside && !tm && s == c->stream && !(diag("pipe", PIPE_DEFAULT_PCT) > 0 && diag("pipe", PIPE_DEFAULT_PCT) < 100);
+        const bool plain = !beside && !tm && (s == c->stream || c->caller_pipelines) && !(diag("pipe", PIPE_DEFAULT_PCT) > 0 && diag("pipe", PIPE_DEFAULT_PCT) < 100);
         const int want_stages = !plain ? 0 : (do_grad ? 3 : (stop_after >= 3 ? 2 : (stop_after >= 2 ? 1 : 0)));
         solved = launch_potrf(ut, pl, kp, gen, s, side, want_stages, want_gc);
         if (beside) HIP_TRY(c, hipStreamWaitValue32(s, w + 7, side.seq, hipStreamWaitValueGte, 0xffffffffu));
@@ -2095,6 +2096,13 @@ int gprf_table_builds(gprf_ctx *c, int32_t *builds) {
     if (c->ev_last) HIP_TRY(c, hipEventSynchronize(c->ev_last));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(builds, res_ctl(c) + CTL_BUILDS, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GPRF_OK;
+}
+
+int gprf_set_stream_pipelines(gprf_ctx *c, int32_t enable) {
+    if (!c) return GPRF_ERR_ARG;
+    c->caller_pipelines = enable != 0;
+    for (gprf_ctx *k : c->kids) k->caller_pipelines = enable != 0;
     return GPRF_OK;
 }
 

@@ -145,6 +145,7 @@ class DeviceEvaluator(object):
         self.h_X = torch.empty(nx, dtype=torch.float64, pin_memory=True)
         self.h_out = torch.empty(no, dtype=torch.float64, pin_memory=True)
         self._work = None              # the all-reduce still in flight on d_out, if any
+        self._pipelines_on = False     # (set by the synchronous form, _round; enqueue() — back-to-back evaluations — leaves it off)
 
     def set_X(self, X):
         with self.torch.cuda.stream(self.stream):
@@ -190,6 +191,10 @@ class DeviceEvaluator(object):
         torch, st = self.torch, self.stream
         no = out_len(self.n, self.dx, self.ncov)
         err = None
+        if not self._pipelines_on:
+            # one evaluation at a time, waited for: the library may pipeline the size classes on this stream as it does on its own
+            self.g._ctx.set_stream_pipelines(True)
+            self._pipelines_on = True
         with torch.cuda.stream(st):
             enqueue = self.g._ctx.objective_device if objective else self.g._ctx.eval_device
             try:

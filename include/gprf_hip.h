@@ -265,6 +265,16 @@ const char *gprf_runtime_config(void);
  * evaluations and returns ms_out[0..6] = average duration per stage over the evaluations recorded since
  * the reset; if n >= 15 also ms_out[7..13] = the last evaluation's durations and ms_out[14] = the count. */
 int gprf_set_timing(gprf_ctx *ctx, int32_t enable);
+/* With these timers ON the library runs every stage as ONE launch over all units, one after the other (what the stage
+ * durations mean).  With them off an evaluation of the kind the reference's drivers issue — gprf_eval / gprf_update_eval /
+ * gprf_objective: host in, host out, one at a time (gprfopt.py:377-417) — pipelines the two size classes of the Cholesky
+ * (gprf.py:520: pdinv; units of more than / at most 13 tiles on two queues) through substitution, At and gradient
+ * (gprf.py:521-584) on those two queues and joins them in front of the assembly (gprf.py:253-288); the results are the
+ * same bits.  gprf_set_stream_pipelines(ctx, 1) asks for the same on a CALLER's stream (gprf_eval_device,
+ * gprf_update_eval_device, gprf_objective_device): for a caller that enqueues one evaluation and waits for it — one
+ * process per GPU, the all-reduce behind every evaluation; default 0: many contexts enqueued back to back on one stream
+ * share the hardware queues of their side streams and lose more than they gain. */
+int gprf_set_stream_pipelines(gprf_ctx *ctx, int32_t enable);
 int gprf_get_timing(gprf_ctx *ctx, int32_t n, double *ms_out);
 #define GPRF_N_STAGES 7
 
