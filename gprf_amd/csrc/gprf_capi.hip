@@ -738,7 +738,13 @@ int enqueue_eval(gprf_ctx *c, const double *d_X, int want_gx, int want_gc, doubl
         // cost that form 12 %)
         const bool plain = !beside && !tm && (s == c->stream || c->caller_pipelines) && !(diag("pipe", PIPE_DEFAULT_PCT) > 0 && diag("pipe", PIPE_DEFAULT_PCT) < 100);
         const int want_stages = !plain ? 0 : (do_grad ? 3 : (stop_after >= 3 ? 2 : (stop_after >= 2 ? 1 : 0)));
-        solved = launch_potrf(ut, pl, kp, gen, s, side, want_stages, want_gc);
+        // (the zero-copy, polled host path on the library's own stream may continue on whichever queue carries the longer
+        // pipeline: the completion word is polled, nothing is waited for on a stream, and the next evaluation is not enqueued
+        // before this one has been seen to finish)
+        const bool may_move = host_io == 1 && stop_after >= 5 && c->spin && c->h_done.p && s == c->stream;
+        hipStream_t tail = s;
+        solved = launch_potrf(ut, pl, kp, gen, s, side, want_stages, want_gc, may_move ? &tail : nullptr);
+        s = tail;
         if (beside) HIP_TRY(c, hipStreamWaitValue32(s, w + 7, side.seq, hipStreamWaitValueGte, 0xffffffffu));
         else launch_big_potrf(ut, pl, kp, s);
     }
@@ -939,6 +945,7 @@ int bounded_stream_wait(gprf_ctx *c, hipStream_t s) {
 }
 
 int finish_eval(gprf_ctx *c, hipStream_t s, int32_t *first_bad_unit, int32_t *reblocked) {
+    if (c->last_stream) s = c->last_stream;      // (an evaluation may end on the side queue: launch_potrf's tail)
     if (c->poll_pending) {
         // spin on the sequence number k_done stores into pinned memory (bounded: fall back to querying the stream)
         volatile int32_t *flag = c->h_done.p;

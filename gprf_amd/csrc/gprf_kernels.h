@@ -219,8 +219,12 @@ struct SideQueue {
 // class_stages: how many of the stages behind the Cholesky the caller wants next (1 solve, 2 + At, 3 + gradient) — a two-queue
 // launch then runs each size class's stages behind that class's Cholesky kernel on its queue and joins the queues behind
 // them (round 6); returns how many it ran (the caller skips those launches)
+// tail (may be nullptr): where the caller may continue.  When all three stages run by class the SIDE queue's pipeline is the longer
+// one; with tail != nullptr the queues then join INTO the side queue (the main queue writes a word behind its last kernel, the
+// side queue waits for it — it has been written long before) and *tail = that queue: the assembly follows the critical
+// pipeline without a cross-queue hop.  Otherwise *tail = s.
 int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side, int class_stages,
-                 int want_gc);
+                 int want_gc, hipStream_t *tail);
 void launch_solve(const UnitTab &ut, const Pools &p, const KParams &kp, hipStream_t s);
 // the forward substitution of ONE of the Cholesky's two size classes (which = 1: the large units + the surplus units of the
 // small list; 2: the small list), and whether a launch is split that way (diag solve_class=0: never)

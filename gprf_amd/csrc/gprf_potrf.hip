@@ -1206,7 +1206,8 @@ static bool potrf_one_queue() {
 }
 
 int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen, hipStream_t s, const SideQueue &side, int class_stages,
-                 int want_gc) {
+                 int want_gc, hipStream_t *tail) {
+    if (tail) *tail = s;
     if (ut.n_ids == 0) return 0;
     hipStream_t s2 = side.s2;
     const int stamps = diag("potrf_stamps", 0);      // diagnostic builds (-DGPRF_PROFILE): in-kernel cycle stamps into Pools::dbg
@@ -1308,6 +1309,13 @@ int launch_potrf(const UnitTab &ut, const Pools &p, const KParams &kp, bool gen,
     if (depth >= 2) launch_at_class(ut, p, 1, s);
     if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 2, s2);
     if (depth >= 3) launch_grad_class(ut, p, kp, want_gc, 1, s);
+    if (s2 != s && tail && depth >= 3 && values && diag("tail_swap", 1) != 0) {
+        // the join INTO the side queue (see the declaration): the wait is submitted behind the write that satisfies it
+        (void)hipStreamWriteValue32(s, side.words + 11, side.seq, 0);
+        (void)hipStreamWaitValue32(s2, side.words + 11, side.seq, hipStreamWaitValueGte, 0xffffffffu);
+        *tail = s2;
+        return depth;      // (nothing of a by-class launch is left for the generic kernel)
+    }
     if (s2 != s) {      // join
         if (values) {
             (void)hipStreamWriteValue32(s2, side.words + 1, side.seq, 0);

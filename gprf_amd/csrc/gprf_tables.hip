@@ -45,6 +45,7 @@ int xcd_grid(int n_ids, int nparts) { return ((n_ids + 7) / 8) * 8 * nparts; }
 //   big_super=<n>   block rows of 64 per super-block of the blocked path (read once per process); big_super_solve=<n>: the sweep's
 //   big_beside=0    the blocked path's Cholesky / substitution behind the one-workgroup kernels instead of beside them (mixed launches)
 //   solve_class=0   every stage behind the Cholesky as ONE launch over all units (rounds 1-5); class_depth=<1..3>: how many of them run by size class
+//   tail_swap=0     the by-class pipelines joined into the main queue (default: into the side queue, which carries the longer pipeline)
 //   tool_env=0      a tool is loaded but does not serialise the queues (rocprofv3 --kernel-trace without counters): keep the product's
 //                   launch structure (scripts/profile_run.sh)          mgrad_group=<G>  the gradient grid walked in groups of G launch slots (0 = launch-wide)
 // Read at every call (a handful of string searches per evaluation): a test may change it between two contexts of one process.

@@ -90,7 +90,7 @@ def test_stages_pipelined_by_size_class_equal_launch_wide_stages_bit_for_bit(tmp
     class_depth=1 / 2 stop the pipelines after the substitution / after At: every result of the walk the same bits"""
     shape = {"VAR_N": str(n), "VAR_BLOCKS": str(blocks)}
     base = run_variant(tmp_path, shape)
-    for d in ("solve_class=0", "class_depth=1", "class_depth=2"):
+    for d in ("solve_class=0", "class_depth=1", "class_depth=2", "tail_swap=0"):
         assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
@@ -105,6 +105,7 @@ def test_launch_variants_agree_bit_for_bit(tmp_path):
                       # round 6: each size class's forward substitution behind its own Cholesky kernel on that kernel's queue (the
                       # small class with a 13-tile instantiation at four workgroups per CU) against ONE launch behind the join
                       ("the substitution as one launch", {"GPRF_DIAG": "solve_class=0"}),
+                      ("the queues joined into the main queue instead of the side queue", {"GPRF_DIAG": "tail_swap=0"}),
                       ("only the substitution by class", {"GPRF_DIAG": "class_depth=1"}),
                       ("substitution and At by class", {"GPRF_DIAG": "class_depth=2"}),
                       ("all of these at once", {"GPRF_DIAG": "fused_build=0,gx_fold=0,one_queue=1,part_major=0"})):
