@@ -821,10 +821,12 @@ void launch_gx_finalize(const UnitTab &ut, const Pools &p, const KParams &kp, in
 void launch_grad_class(const UnitTab &ut, const Pools &p, const KParams &kp, int want_gc, int which, hipStream_t s) {
     const int TBm = (ut.max_T + 3) / 4, nbp = TBm * (TBm + 1) / 2;
     UnitTab utp = ut;
-    utp.pm_group = 0;
+    // (a launch more than two rounds of CUs deep is walked in groups of 64 slots, like launch_grad's: L2 residency)
+    const int G = ut.n_launch > 2 * device_cus() ? 64 : 0;
+    utp.pm_group = G;
     const int n = which == 1 ? ut.grid_big : ut.grid_small;
     if (n <= 0) return;
-    dim3 grid(xcd_grid(n, nbp));
+    dim3 grid(G > 0 ? ((n + G - 1) / G) * G * nbp : xcd_grid(n, nbp));
     if (which == 1) {
         if (want_gc) hipLaunchKernelGGL((k_mgrad<0, 0, false, 2, false, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
         else hipLaunchKernelGGL((k_mgrad<0, 0, false, 1, false, 1>), grid, dim3(256), 0, s, utp, p, kp, want_gc, 1);
