@@ -94,6 +94,43 @@ def test_stages_pipelined_by_size_class_equal_launch_wide_stages_bit_for_bit(tmp
         assert run_variant(tmp_path, dict(shape, GPRF_DIAG=d)) == base, d
 
 
+DX3_DRIVER = r'''
+import sys
+import numpy as np
+from gprf_amd import GPCov
+from gprf_amd.gprf import GPRF
+rng = np.random.RandomState(3)
+n = 1000
+X = rng.rand(n, 3)
+Y = rng.randn(n, 6)
+order = np.argsort(X[:, 0], kind="stable")
+blocks = [np.sort(order[k * 125:(k + 1) * 125]) for k in range(8)]        # eight slabs of 125 points: pairs of 250 = 16 tiles
+nbrs = [(k + 1, k) for k in range(7)]
+g = GPRF(X, Y, None, GPCov([1.0], [0.3, 0.25, 0.35], "euclidean", "se"), 0.02, block_idxs=blocks, neighbors=nbrs)
+ll, gX, gC = g.llgrad(grad_X=True, grad_cov=True)
+np.savez(sys.argv[1], ll=ll, gX=gX, gC=gC)
+g.close()
+'''
+
+
+def test_three_dimensional_inputs_through_the_by_class_pipelines(tmp_path):
+    """dx = 3: the gradient kernel's general instantiation has no class form, so the pipelines stop behind At (class_depth is
+    capped at 2) and the gradient runs launch-wide behind the join — against every stage launch-wide, bit for bit"""
+    import numpy as np
+    (tmp_path / "dx3.py").write_text(DX3_DRIVER)
+    out = {}
+    for tag, env in (("by class", {}), ("launch wide", {"GPRF_DIAG": "solve_class=0"})):
+        e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        e.update(env)
+        f = str(tmp_path / (tag.replace(" ", "_") + ".npz"))
+        r = subprocess.run([sys.executable, str(tmp_path / "dx3.py"), f], cwd=str(tmp_path), env=e, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        out[tag] = np.load(f)
+    a, b = out["by class"], out["launch wide"]
+    assert float(a["ll"]) == float(b["ll"]) and np.array_equal(a["gX"], b["gX"]) and np.array_equal(a["gC"], b["gC"])
+
+
 def test_launch_variants_agree_bit_for_bit(tmp_path):
     base = run_variant(tmp_path, {})
     for name, env in (("three-launch table build", {"GPRF_DIAG": "fused_build=0"}),
